@@ -1,0 +1,22 @@
+"""codesign-kernels_amd -- MI355X-native E3SM-MMF 2D MPDATA tracer advection.
+
+Host-side mirror (Python) of the one routine this project replaces:
+`advect_scalar2D(f,u,w,rho,rhow,flux)` of the reference
+mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90 (:72, :247, :477),
+bound to libmpdata_hip.so (hand-written HIP for gfx950) through the C-ABI in
+include/mpdata_hip.h.  The Fortran driver + shim that north_star asks for live
+in fortran/; this Python face exists for bench.py, the tests and
+torch.distributed plumbing.  There is no CPU fallback here: if the HIP library
+is missing or no device is usable, calls raise.
+"""
+from .capi import (MpdataError, Plan, VARIANT_EXACT, VARIANT_FAST, advect_scalar2D,
+                   advect_scalar2D_host, algorithmic_bytes, build_library, device_count,
+                   fill_synthetic, get_variant, lib, lib_path, pack_shard, set_tile,
+                   set_variant, shapes, unpack_shard)
+from .shard import gather_outputs, partition, scatter_inputs
+
+__all__ = ["MpdataError", "Plan", "VARIANT_EXACT", "VARIANT_FAST", "advect_scalar2D",
+           "advect_scalar2D_host", "algorithmic_bytes", "build_library", "device_count",
+           "fill_synthetic", "get_variant", "lib", "lib_path", "pack_shard", "set_tile",
+           "set_variant", "shapes", "unpack_shard", "partition", "scatter_inputs",
+           "gather_outputs"]

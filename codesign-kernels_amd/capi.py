@@ -1,0 +1,259 @@
+"""ctypes binding of libmpdata_hip.so (include/mpdata_hip.h) and the Python
+mirror of the reference's operator interface.
+
+Array convention.  The reference declares (Fortran, column-major, `sl`
+fastest; reference :479-484, :30)
+    f(ncrms,-2:nx+3,1,nzm)  u(ncrms,-1:nx+3,1,nzm)  w(ncrms,-1:nx+2,1,nz)
+    rho(ncrms,nzm)  rhow(ncrms,nz)  adz(ncrms,nzm)  flux(ncrms,nz)
+The same bytes are
+  * numpy: Fortran-ordered arrays of shape (ncrms, nx+6, nzm[, ntracers]) ...
+  * torch: C-contiguous tensors with the axes reversed,
+           ([ntracers,] nzm, nx+6, ncrms) ...
+so a device tensor's last axis is the coalesced CRM-instance axis.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(HERE, "libmpdata_hip.so")
+VARIANT_EXACT, VARIANT_FAST = 0, 1
+
+_lib = None
+
+
+class MpdataError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmpdata_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 the kernels + C-ABI into libmpdata_hip.so
+    (cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(HERE, "csrc"), "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise MpdataError(-100, f"{_LIB_PATH} not built; run __graft_entry__.build() "
+                                    "(make -C codesign-kernels_amd/csrc)")
+        L = ctypes.CDLL(_LIB_PATH)
+        dp, vp = ctypes.c_void_p, ctypes.c_void_p
+        i64, ci = ctypes.c_int64, ctypes.c_int
+        L.mpdata_advect_scalar2d.restype = ci
+        L.mpdata_advect_scalar2d.argtypes = [i64, ci, ci, ci] + [dp] * 7
+        L.mpdata_advect_scalar2d_device.restype = ci
+        L.mpdata_advect_scalar2d_device.argtypes = [i64, ci, ci, ci] + [dp] * 7 + [vp]
+        L.mpdata_plan_create.restype = ci
+        L.mpdata_plan_create.argtypes = [i64, ci, ci, ci, ctypes.POINTER(vp)]
+        L.mpdata_plan_upload.restype = ci
+        L.mpdata_plan_upload.argtypes = [vp] + [dp] * 7
+        for name in ("mpdata_plan_run", "mpdata_plan_sync", "mpdata_plan_destroy"):
+            getattr(L, name).restype = ci
+            getattr(L, name).argtypes = [vp]
+        L.mpdata_plan_download.restype = ci
+        L.mpdata_plan_download.argtypes = [vp, dp, dp]
+        L.mpdata_plan_last_kernel_ms.restype = ci
+        L.mpdata_plan_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        L.mpdata_fill_synthetic_device.restype = ci
+        L.mpdata_fill_synthetic_device.argtypes = [dp, ci, i64, i64, i64, i64, ctypes.c_uint64, ci, vp]
+        L.mpdata_pack_shard_device.restype = ci
+        L.mpdata_pack_shard_device.argtypes = [dp, dp, i64, i64, i64, i64, vp]
+        L.mpdata_unpack_shard_device.restype = ci
+        L.mpdata_unpack_shard_device.argtypes = [dp, dp, i64, i64, i64, i64, vp]
+        L.mpdata_set_variant.restype = ci
+        L.mpdata_set_variant.argtypes = [ci]
+        L.mpdata_get_variant.restype = ci
+        L.mpdata_set_tile.restype = ci
+        L.mpdata_set_tile.argtypes = [ci]
+        L.mpdata_device_count.restype = ci
+        L.mpdata_algorithmic_bytes.restype = i64
+        L.mpdata_algorithmic_bytes.argtypes = [i64, ci, ci, ci]
+        L.mpdata_last_error.restype = ctypes.c_char_p
+        L.mpdata_version.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MpdataError(rc, lib().mpdata_last_error().decode())
+
+
+def set_variant(v):
+    return lib().mpdata_set_variant(int(v))
+
+
+def get_variant():
+    return lib().mpdata_get_variant()
+
+
+def set_tile(t):
+    return lib().mpdata_set_tile(int(t))
+
+
+def device_count():
+    return lib().mpdata_device_count()
+
+
+def algorithmic_bytes(ncrms, nx, nz, ntracers=1):
+    return int(lib().mpdata_algorithmic_bytes(ncrms, nx, nz, ntracers))
+
+
+SID = {"adz": 0, "f": 1, "u": 2, "w": 3, "rho": 4, "rhow": 5, "flux": 6}
+
+
+def shapes(ncrms, nx, nz, ntracers=1):
+    """torch-side (C-order, reversed axes) shapes of the seven arrays."""
+    nzm = nz - 1
+    t = (ntracers,) if ntracers > 1 else ()
+    return {"adz": (nzm, ncrms), "f": t + (nzm, nx + 6, ncrms), "u": (nzm, nx + 5, ncrms),
+            "w": (nz, nx + 4, ncrms), "rho": (nzm, ncrms), "rhow": (nz, ncrms),
+            "flux": t + (nz, ncrms)}
+
+
+def _stream_handle(stream):
+    import torch
+    s = torch.cuda.current_stream() if stream is None else stream
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _dims_from(f, u):
+    """(ncrms, nx, nz, ntracers) from torch tensors in the reversed-axes layout."""
+    nt = f.shape[0] if f.dim() == 4 else 1
+    nzm, nxp6, ncrms = f.shape[-3:]
+    if tuple(u.shape) != (nzm, nxp6 - 1, ncrms):
+        raise MpdataError(-1, f"u shape {tuple(u.shape)} does not match f {tuple(f.shape)}")
+    return ncrms, nxp6 - 6, nzm + 1, nt
+
+
+def _dev_ptr(t, shape, name):
+    import torch
+    if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise MpdataError(-1, f"{name}: need a contiguous float64 device tensor")
+    if tuple(t.shape) != tuple(shape):
+        raise MpdataError(-1, f"{name}: shape {tuple(t.shape)} != expected {tuple(shape)}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def advect_scalar2D(f, u, w, rho, rhow, flux, adz, stream=None):
+    """Device-resident `call advect_scalar2D(f,u,w,rho,rhow,flux)` (reference
+    :53/:57; adz is host-associated there, :30).  torch float64 device tensors
+    in the reversed-axes layout; f and flux are updated in place; asynchronous
+    on `stream` (default: torch's current stream)."""
+    ncrms, nx, nz, nt = _dims_from(f, u)
+    sh = shapes(ncrms, nx, nz, nt)
+    ptrs = [_dev_ptr(t, sh[k], k) for k, t in
+            (("f", f), ("u", u), ("w", w), ("rho", rho), ("rhow", rhow), ("adz", adz), ("flux", flux))]
+    _check(lib().mpdata_advect_scalar2d_device(ncrms, nx, nz, nt, *ptrs, _stream_handle(stream)))
+
+
+def _host_ptr(a, name, writable=False):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["F_CONTIGUOUS"]):
+        raise MpdataError(-1, f"{name}: need a Fortran-ordered float64 numpy array")
+    if writable and not a.flags["WRITEABLE"]:
+        raise MpdataError(-1, f"{name}: not writable")
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _host_dims(f):
+    ncrms, nxp6, nzm = f.shape[:3]
+    nt = f.shape[3] if f.ndim == 4 else 1
+    return ncrms, nxp6 - 6, nzm + 1, nt
+
+
+def advect_scalar2D_host(f, u, w, rho, rhow, flux, adz):
+    """The drop-in, synchronous call on HOST arrays (numpy, Fortran order,
+    reference shapes): H2D + kernel + D2H, like the reference's OpenACC
+    routine with its update device/host directives (:107, :241)."""
+    ncrms, nx, nz, nt = _host_dims(f)
+    _check(lib().mpdata_advect_scalar2d(
+        ncrms, nx, nz, nt, _host_ptr(f, "f", True), _host_ptr(u, "u"), _host_ptr(w, "w"),
+        _host_ptr(rho, "rho"), _host_ptr(rhow, "rhow"), _host_ptr(adz, "adz"),
+        _host_ptr(flux, "flux", True)))
+
+
+class Plan:
+    """Library-owned device buffers + stream (reference: `!$acc enter data`,
+    `update device`, `wait`, `update host`; :105-110, :237-242)."""
+
+    def __init__(self, ncrms, nx, nz, ntracers=1):
+        self._p = ctypes.c_void_p()
+        _check(lib().mpdata_plan_create(ncrms, nx, nz, ntracers, ctypes.byref(self._p)))
+
+    def upload(self, f, u, w, rho, rhow, adz, flux=None):
+        fl = _host_ptr(flux, "flux") if flux is not None else None
+        _check(lib().mpdata_plan_upload(self._p, _host_ptr(f, "f"), _host_ptr(u, "u"),
+                                        _host_ptr(w, "w"), _host_ptr(rho, "rho"),
+                                        _host_ptr(rhow, "rhow"), _host_ptr(adz, "adz"), fl))
+
+    def run(self):
+        _check(lib().mpdata_plan_run(self._p))
+
+    def sync(self):
+        _check(lib().mpdata_plan_sync(self._p))
+
+    def download(self, f, flux):
+        _check(lib().mpdata_plan_download(self._p, _host_ptr(f, "f", True),
+                                          _host_ptr(flux, "flux", True)))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_double()
+        _check(lib().mpdata_plan_last_kernel_ms(self._p, ctypes.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._p:
+            lib().mpdata_plan_destroy(self._p)
+            self._p = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fill_synthetic(t, name, seed, dist, ncrms_global=None, sl0=0, stream=None):
+    """Fill device tensor `t` (reversed-axes layout, last axis = local CRM
+    instances) with the synthetic law of array `name`."""
+    nloc = t.shape[-1]
+    rows = t.numel() // nloc
+    ng = nloc if ncrms_global is None else ncrms_global
+    _check(lib().mpdata_fill_synthetic_device(ctypes.c_void_p(t.data_ptr()), SID[name], rows, ng,
+                                              sl0, nloc, seed, dist, _stream_handle(stream)))
+
+
+def pack_shard(full, sl0, nloc, out=None, stream=None):
+    """Contiguous copy of CRM instances [sl0, sl0+nloc) of a device tensor."""
+    import torch
+    ncrms = full.shape[-1]
+    rows = full.numel() // ncrms
+    if out is None:
+        out = torch.empty(full.shape[:-1] + (nloc,), dtype=full.dtype, device=full.device)
+    _check(lib().mpdata_pack_shard_device(ctypes.c_void_p(full.data_ptr()),
+                                          ctypes.c_void_p(out.data_ptr()), rows, ncrms, sl0, nloc,
+                                          _stream_handle(stream)))
+    return out
+
+
+def unpack_shard(full, shard, sl0, stream=None):
+    ncrms, nloc = full.shape[-1], shard.shape[-1]
+    rows = full.numel() // ncrms
+    _check(lib().mpdata_unpack_shard_device(ctypes.c_void_p(full.data_ptr()),
+                                            ctypes.c_void_p(shard.data_ptr()), rows, ncrms, sl0,
+                                            nloc, _stream_handle(stream)))

@@ -1,0 +1,35 @@
+// mpdata_args.h -- kernel argument block shared by host and device code.
+#ifndef MPDATA_ARGS_H
+#define MPDATA_ARGS_H
+
+// Arrays are the reference's dummy arguments (reference
+// mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:479-484) plus the
+// host-associated adz (:30); see include/mpdata_hip.h for the layout.
+struct MpdataArgs {
+  double* f;
+  const double* u;
+  const double* w;
+  const double* rho;
+  const double* rhow;
+  const double* adz;
+  double* flux;
+  long long ncrms;         // CRM instances = leading dimension of every array
+  int nx, nz;
+  long long f_tstride;     // elements between consecutive tracers of f
+  long long flux_tstride;  // ... of flux
+};
+
+// One tiling of the kernel template (W columns per thread, SPW strips per
+// wave, NWV waves per workgroup).
+struct MpdataTileInfo {
+  int id;
+  int W, SPW, NWV;
+  int slw;      // CRM instances per workgroup
+  int ncol;     // columns covered (needs nx + 4 <= ncol)
+  int threads;
+  const char* name;
+};
+
+typedef void (*mpdata_launch_fn)(const MpdataArgs& a, int ntracers, void* stream);
+
+#endif

@@ -1,0 +1,381 @@
+// mpdata_capi.hip -- the C-ABI of libmpdata_hip.so (include/mpdata_hip.h):
+// argument validation, tiling choice, plan/buffer management, the synthetic
+// input generator and the shard pack/unpack kernels.  No CPU compute path
+// exists in this library: every entry point either runs HIP kernels or
+// returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "mpdata_args.h"
+#include "mpdata_hip.h"
+
+namespace mpdata_exact {
+int num_tiles();
+bool tile_info(int id, MpdataTileInfo* info);
+bool launch(int id, const MpdataArgs& a, int ntracers, void* stream);
+}  // namespace mpdata_exact
+namespace mpdata_fast {
+int num_tiles();
+bool tile_info(int id, MpdataTileInfo* info);
+bool launch(int id, const MpdataArgs& a, int ntracers, void* stream);
+}  // namespace mpdata_fast
+
+namespace {
+
+thread_local std::string g_err;
+int g_variant = -1;  // -1: read MPDATA_VARIANT on first use
+int g_tile = -2;     // -2: read MPDATA_TILE on first use; -1: automatic
+
+int set_err(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+int hip_err(hipError_t e, const char* what) {
+  return set_err((int)e, "%s: %s", what, hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t e_ = (expr);                            \
+    if (e_ != hipSuccess) return hip_err(e_, #expr);   \
+  } while (0)
+
+int variant() {
+  if (g_variant < 0) {
+    const char* v = getenv("MPDATA_VARIANT");
+    g_variant = (v && (!strcmp(v, "fast") || !strcmp(v, "1"))) ? MPDATA_VARIANT_FAST
+                                                               : MPDATA_VARIANT_EXACT;
+  }
+  return g_variant;
+}
+int tile_override() {
+  if (g_tile == -2) {
+    const char* v = getenv("MPDATA_TILE");
+    g_tile = v ? atoi(v) : -1;
+  }
+  return g_tile;
+}
+
+bool get_tile(int var, int id, MpdataTileInfo* t) {
+  return var == MPDATA_VARIANT_FAST ? mpdata_fast::tile_info(id, t) : mpdata_exact::tile_info(id, t);
+}
+
+// Smallest column coverage that fits nx (needs nx+4 <= ncol); ties -> lowest id.
+int choose_tile(int var, int nx, MpdataTileInfo* out) {
+  const int forced = tile_override();
+  MpdataTileInfo t;
+  if (forced >= 0) {
+    if (!get_tile(var, forced, &t)) return set_err(MPDATA_EINVAL, "unknown tile id %d", forced);
+    if (t.ncol < nx + 4)
+      return set_err(MPDATA_EUNSUPPORTED, "tile %s covers %d columns, nx=%d needs %d", t.name,
+                     t.ncol, nx, nx + 4);
+    *out = t;
+    return 0;
+  }
+  int best = -1, best_ncol = 1 << 30;
+  const int n = var == MPDATA_VARIANT_FAST ? mpdata_fast::num_tiles() : mpdata_exact::num_tiles();
+  for (int id = 0; id < n; ++id) {
+    if (!get_tile(var, id, &t)) continue;
+    if (t.ncol >= nx + 4 && t.ncol < best_ncol) { best = id; best_ncol = t.ncol; }
+  }
+  if (best < 0)
+    return set_err(MPDATA_EUNSUPPORTED, "nx=%d exceeds the widest kernel tiling", nx);
+  get_tile(var, best, out);
+  return 0;
+}
+
+int validate(int64_t ncrms, int nx, int nz, int ntracers) {
+  if (ncrms < 1 || nx < 1 || nz < 3 || ntracers < 1)
+    return set_err(MPDATA_EINVAL, "bad sizes ncrms=%lld nx=%d nz=%d ntracers=%d (need >=1,>=1,>=3,>=1)",
+                   (long long)ncrms, nx, nz, ntracers);
+  // 32-bit byte offsets inside one k-plane (kernel uses buffer addressing)
+  if ((double)ncrms * (nx + 8) * 8.0 >= 2147483648.0)
+    return set_err(MPDATA_EUNSUPPORTED, "ncrms*(nx+8)*8 must be < 2^31 bytes per k-plane");
+  if (ntracers > 65535) return set_err(MPDATA_EUNSUPPORTED, "ntracers > 65535");
+  return 0;
+}
+
+struct Sizes {
+  size_t f, u, w, k, kz;  // elements
+};
+Sizes sizes_of(int64_t ncrms, int nx, int nz, int ntracers) {
+  Sizes s;
+  const size_t n = (size_t)ncrms, nzm = (size_t)nz - 1;
+  s.f = n * (nx + 6) * nzm * (size_t)ntracers;
+  s.u = n * (nx + 5) * nzm;
+  s.w = n * (nx + 4) * (size_t)nz;
+  s.k = n * nzm;
+  s.kz = n * (size_t)nz;
+  return s;
+}
+
+// ---- synthetic generator (same law as oracle/mpdata_oracle.c:mpdata_oracle_fill)
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void fill_kernel(double* a, unsigned long long base, double shift, long long rows,
+                            long long ng, long long sl0, long long nloc) {
+  const long long total = rows * nloc;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long r = t / nloc, s = t - r * nloc;
+    const unsigned long long j = (unsigned long long)(r * ng + sl0 + s);
+    const unsigned long long z = mix64(base + (j + 1) * 0x9E3779B97F4A7C15ull);
+    a[t] = __dadd_rn((double)(z >> 11) * 0x1.0p-53, shift);
+  }
+}
+
+__global__ void pack_kernel(const double* full, double* shard, long long rows, long long ncrms,
+                            long long sl0, long long nloc, int unpack) {
+  const long long total = rows * nloc;
+  double* fullw = const_cast<double*>(full);
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long r = t / nloc, s = t - r * nloc;
+    if (unpack) fullw[r * ncrms + sl0 + s] = shard[t];
+    else shard[t] = full[r * ncrms + sl0 + s];
+  }
+}
+
+unsigned grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  const long long cap = 256 * 8;  // 256 CUs x 8 blocks, grid-stride the rest
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+struct mpdata_plan {
+  int64_t ncrms;
+  int nx, nz, ntracers;
+  Sizes sz;
+  double *f, *u, *w, *rho, *rhow, *adz, *flux;
+  hipStream_t stream;
+  hipEvent_t ev0, ev1;
+  bool uploaded, ran;
+};
+
+extern "C" {
+
+int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers, double* f,
+                                  const double* u, const double* w, const double* rho,
+                                  const double* rhow, const double* adz, double* flux,
+                                  void* stream) {
+  int rc = validate(ncrms, nx, nz, ntracers);
+  if (rc) return rc;
+  if (!f || !u || !w || !rho || !rhow || !adz || !flux)
+    return set_err(MPDATA_EINVAL, "null array pointer");
+  const int var = variant();
+  MpdataTileInfo t;
+  rc = choose_tile(var, nx, &t);
+  if (rc) return rc;
+  MpdataArgs a;
+  a.f = f; a.u = u; a.w = w; a.rho = rho; a.rhow = rhow; a.adz = adz; a.flux = flux;
+  a.ncrms = ncrms; a.nx = nx; a.nz = nz;
+  a.f_tstride = (long long)ncrms * (nx + 6) * (nz - 1);
+  a.flux_tstride = (long long)ncrms * nz;
+  const bool ok = var == MPDATA_VARIANT_FAST ? mpdata_fast::launch(t.id, a, ntracers, stream)
+                                             : mpdata_exact::launch(t.id, a, ntracers, stream);
+  if (!ok) return set_err(MPDATA_EINVAL, "tile %d not instantiated", t.id);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int mpdata_plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan) {
+  if (!plan) return set_err(MPDATA_EINVAL, "null plan pointer");
+  *plan = nullptr;
+  int rc = validate(ncrms, nx, nz, ntracers);
+  if (rc) return rc;
+  MpdataTileInfo t;
+  rc = choose_tile(variant(), nx, &t);
+  if (rc) return rc;
+  mpdata_plan* p = (mpdata_plan*)calloc(1, sizeof(mpdata_plan));
+  if (!p) return set_err(MPDATA_EINVAL, "out of host memory");
+  p->ncrms = ncrms; p->nx = nx; p->nz = nz; p->ntracers = ntracers;
+  p->sz = sizes_of(ncrms, nx, nz, ntracers);
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = hipMalloc((void**)&p->f, p->sz.f * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->u, p->sz.u * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->w, p->sz.w * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->rho, p->sz.k * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->rhow, p->sz.kz * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->adz, p->sz.k * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->flux, p->sz.kz * ntracers * 8);
+  if (e == hipSuccess) e = hipStreamCreate(&p->stream);
+  if (e == hipSuccess) e = hipEventCreate(&p->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+  if (e != hipSuccess) {
+    mpdata_plan_destroy(p);
+    return hip_err(e, "mpdata_plan_create");
+  }
+  *plan = p;
+  return 0;
+}
+
+int mpdata_plan_upload(mpdata_plan* p, const double* f, const double* u, const double* w,
+                       const double* rho, const double* rhow, const double* adz,
+                       const double* flux) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (!f || !u || !w || !rho || !rhow || !adz) return set_err(MPDATA_EINVAL, "null array pointer");
+  HIP_TRY(hipMemcpyAsync(p->f, f, p->sz.f * 8, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->u, u, p->sz.u * 8, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->w, w, p->sz.w * 8, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->rho, rho, p->sz.k * 8, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->rhow, rhow, p->sz.kz * 8, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->adz, adz, p->sz.k * 8, hipMemcpyHostToDevice, p->stream));
+  // flux is intent(out) in the reference but its level nz is never written
+  // (reference :541, :624 touch 1..nzm only): carry the caller's values over
+  if (flux)
+    HIP_TRY(hipMemcpyAsync(p->flux, flux, p->sz.kz * p->ntracers * 8, hipMemcpyHostToDevice, p->stream));
+  else
+    HIP_TRY(hipMemsetAsync(p->flux, 0, p->sz.kz * p->ntracers * 8, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->uploaded = true;
+  return 0;
+}
+
+int mpdata_plan_run(mpdata_plan* p) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run before mpdata_plan_upload");
+  HIP_TRY(hipEventRecord(p->ev0, p->stream));
+  int rc = mpdata_advect_scalar2d_device(p->ncrms, p->nx, p->nz, p->ntracers, p->f, p->u, p->w,
+                                         p->rho, p->rhow, p->adz, p->flux, (void*)p->stream);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(p->ev1, p->stream));
+  p->ran = true;
+  return 0;
+}
+
+int mpdata_plan_sync(mpdata_plan* p) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int mpdata_plan_download(mpdata_plan* p, double* f, double* flux) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_download before upload");
+  if (f) HIP_TRY(hipMemcpyAsync(f, p->f, p->sz.f * 8, hipMemcpyDeviceToHost, p->stream));
+  if (flux)
+    HIP_TRY(hipMemcpyAsync(flux, p->flux, p->sz.kz * p->ntracers * 8, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int mpdata_plan_last_kernel_ms(mpdata_plan* p, double* ms) {
+  if (!p || !ms) return set_err(MPDATA_EINVAL, "null argument");
+  if (!p->ran) return set_err(MPDATA_ESTATE, "no run recorded");
+  HIP_TRY(hipEventSynchronize(p->ev1));
+  float t = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t, p->ev0, p->ev1));
+  *ms = t;
+  return 0;
+}
+
+int mpdata_plan_destroy(mpdata_plan* p) {
+  if (!p) return 0;
+  if (p->f) (void)hipFree(p->f);
+  if (p->u) (void)hipFree(p->u);
+  if (p->w) (void)hipFree(p->w);
+  if (p->rho) (void)hipFree(p->rho);
+  if (p->rhow) (void)hipFree(p->rhow);
+  if (p->adz) (void)hipFree(p->adz);
+  if (p->flux) (void)hipFree(p->flux);
+  if (p->ev0) (void)hipEventDestroy(p->ev0);
+  if (p->ev1) (void)hipEventDestroy(p->ev1);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  free(p);
+  return 0;
+}
+
+int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* f, const double* u,
+                           const double* w, const double* rho, const double* rhow,
+                           const double* adz, double* flux) {
+  if (!flux) return set_err(MPDATA_EINVAL, "null array pointer");
+  mpdata_plan* p = nullptr;
+  int rc = mpdata_plan_create(ncrms, nx, nz, ntracers, &p);
+  if (rc) return rc;
+  rc = mpdata_plan_upload(p, f, u, w, rho, rhow, adz, flux);
+  if (!rc) rc = mpdata_plan_run(p);
+  if (!rc) rc = mpdata_plan_download(p, f, flux);
+  mpdata_plan_destroy(p);
+  return rc;
+}
+
+int mpdata_fill_synthetic_device(double* a, int sid, int64_t rows, int64_t ncrms_global,
+                                 int64_t sl0, int64_t nloc, uint64_t seed, int dist,
+                                 void* stream) {
+  if (!a || sid < 0 || sid > 6 || rows < 1 || nloc < 1 || sl0 < 0 || sl0 + nloc > ncrms_global ||
+      dist < 1 || dist > 3)
+    return set_err(MPDATA_EINVAL, "bad argument to mpdata_fill_synthetic_device");
+  double shift = 0.0;
+  if (dist == 1) {
+    if (sid == 2 || sid == 3) shift = -0.5;
+    else if (sid == 0 || sid == 4 || sid == 5) shift = 0.5;
+  } else if (dist == 3) {
+    if (sid == 2 || sid == 3) shift = -0.5;
+  }
+  const unsigned long long base = seed + (unsigned long long)sid * 0xD1B54A32D192ED03ull;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(rows * nloc, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a, base, shift, (long long)rows, (long long)ncrms_global,
+                     (long long)sl0, (long long)nloc);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int pack_common(const double* full, double* shard, int64_t rows, int64_t ncrms, int64_t sl0,
+                       int64_t nloc, void* stream, int unpack) {
+  if (!full || !shard || rows < 1 || nloc < 1 || sl0 < 0 || sl0 + nloc > ncrms)
+    return set_err(MPDATA_EINVAL, "bad argument to mpdata_(un)pack_shard_device");
+  hipLaunchKernelGGL(pack_kernel, dim3(grid_for(rows * nloc, 256)), dim3(256), 0,
+                     (hipStream_t)stream, full, shard, (long long)rows, (long long)ncrms,
+                     (long long)sl0, (long long)nloc, unpack);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int mpdata_pack_shard_device(const double* full, double* shard, int64_t rows, int64_t ncrms,
+                             int64_t sl0, int64_t nloc, void* stream) {
+  return pack_common(full, shard, rows, ncrms, sl0, nloc, stream, 0);
+}
+int mpdata_unpack_shard_device(double* full, const double* shard, int64_t rows, int64_t ncrms,
+                               int64_t sl0, int64_t nloc, void* stream) {
+  return pack_common(full, const_cast<double*>(shard), rows, ncrms, sl0, nloc, stream, 1);
+}
+
+int mpdata_set_variant(int v) {
+  const int prev = variant();
+  if (v == MPDATA_VARIANT_EXACT || v == MPDATA_VARIANT_FAST) g_variant = v;
+  return prev;
+}
+int mpdata_get_variant(void) { return variant(); }
+int mpdata_set_tile(int tile) {
+  const int prev = tile_override();
+  g_tile = tile < 0 ? -1 : tile;
+  return prev;
+}
+int mpdata_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+// minimal HBM traffic of one call, in bytes.
+int64_t mpdata_algorithmic_bytes(int64_t ncrms, int nx, int nz, int ntracers) {
+  const int64_t nzm = nz - 1;
+  return ncrms * 8 * nzm * ((int64_t)ntracers * (2 * nx + 11) + 2 * nx + 12);
+}
+const char* mpdata_last_error(void) { return g_err.c_str(); }
+const char* mpdata_version(void) { return "mpdata-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+/*
+ * mpdata_hip.h -- C-ABI of libmpdata_hip.so: the MI355X (gfx950) replacement
+ * for the compute body of the E3SM-MMF 2D MPDATA tracer-advection routine.
+ *
+ * What it replaces in the reference (E3SM-Project/codesign-kernels):
+ *   mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90
+ *     :72-244   subroutine advect_scalar2D_openacc_2   (8 OpenACC kernels)
+ *     :247-474  subroutine advect_scalar2D_openacc_1   (17 OpenACC kernels)
+ *   both of which compute what :477-642 advect_scalar2D_cpu computes, and
+ *   mmf-mpdata-tracer/Makefile:17-20 (the `pgiacc` accelerator target).
+ *
+ * Array contract (identical to the reference's dummy arguments, :479-484, and
+ * the host-associated global adz, :30).  Fortran column-major, the CRM
+ * instance index `sl` (reference: nslices; here: ncrms) FASTEST, fp64:
+ *   f   (ncrms, -2:nx+3, 1, nzm [, ntracers])  inout
+ *   u   (ncrms, -1:nx+3, 1, nzm)               in
+ *   w   (ncrms, -1:nx+2, 1, nz )               in   (level nz never read)
+ *   rho (ncrms, nzm)  rhow(ncrms, nz)  adz(ncrms, nzm)   in
+ *   flux(ncrms, nz [, ntracers])               out  (levels 1..nzm written;
+ *                                                    level nz left untouched,
+ *                                                    as the reference does)
+ * with nzm = nz-1.  On return f holds: interior columns 1..nx = the advected
+ * field; halo columns -1,0,nx+1,nx+2 = the first-pass (upwind) value;
+ * columns -2 and nx+3 unchanged -- exactly the reference's in-place result.
+ * `ntracers` > 1 is this library's extension: the same u,w,rho,rhow,adz
+ * applied to ntracers fields, tracer index slowest.
+ *
+ * All functions return 0 on success, a negative MPDATA_E* code on argument
+ * errors, or a positive hipError_t value; mpdata_last_error() gives text.
+ * Nothing here falls back to a CPU path: without a usable HIP device the
+ * calls fail.
+ */
+#ifndef MPDATA_HIP_H
+#define MPDATA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPDATA_EINVAL (-1)      /* bad sizes / null pointer */
+#define MPDATA_EUNSUPPORTED (-2) /* shape outside what the kernels cover */
+#define MPDATA_ESTATE (-3)      /* plan used before upload, etc. */
+
+/* kernel variants (mpdata_set_variant / MPDATA_VARIANT env): */
+#define MPDATA_VARIANT_EXACT 0  /* no FMA contraction, IEEE divide, reference
+                                   summation order: bit-identical to the
+                                   reference CPU routine built with
+                                   -ffp-contract=off */
+#define MPDATA_VARIANT_FAST 1   /* FMA contraction allowed; differs from the
+                                   above by rounding only (< 1e-12 abs on
+                                   conditioned inputs) */
+
+/* ---- 1. Drop-in call: host arrays, synchronous, transfers included. -------
+ * Replaces `call advect_scalar2D_openacc_N(f,u,w,rho,rhow,flux)` (reference
+ * :53,:57) including its `!$acc update device/host` traffic (:107,:241).
+ * Sizes and adz, which the reference routine takes by host association
+ * (:7-30), are explicit arguments here. */
+int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers,
+                           double* f, const double* u, const double* w,
+                           const double* rho, const double* rhow,
+                           const double* adz, double* flux);
+
+/* ---- 2. Device-resident call: device pointers, asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream).  This is the
+ * reference's timed region (:110-238: kernels only, data already on the
+ * device).  Arrays cover `ncrms` CRM instances with leading dimension
+ * `ncrms`.  In-place on f. */
+int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers,
+                                  double* f, const double* u, const double* w,
+                                  const double* rho, const double* rhow,
+                                  const double* adz, double* flux, void* stream);
+
+/* ---- 3. Plan API: device buffers owned by the library (what the OpenACC
+ * `enter data pcreate` / `update device` / `update host` directives do,
+ * reference :105-107, :241, :662-663). */
+typedef struct mpdata_plan mpdata_plan;
+int mpdata_plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan);
+int mpdata_plan_upload(mpdata_plan* plan, const double* f, const double* u, const double* w,
+                       const double* rho, const double* rhow, const double* adz,
+                       const double* flux);
+int mpdata_plan_run(mpdata_plan* plan);            /* async on the plan's stream */
+int mpdata_plan_sync(mpdata_plan* plan);           /* the `!$acc wait` (:237) */
+int mpdata_plan_download(mpdata_plan* plan, double* f, double* flux);
+int mpdata_plan_last_kernel_ms(mpdata_plan* plan, double* ms); /* hipEvent time of the last run */
+int mpdata_plan_destroy(mpdata_plan* plan);
+
+/* ---- 4. Synthetic inputs on the device (bench/tests; the reference's init,
+ * :645-660, with a portable counter-based generator instead of the
+ * compiler's random_number).  Fills `rows` x `nloc` doubles of array `sid`
+ * (0..6 = adz,f,u,w,rho,rhow,flux) for CRM instances [sl0, sl0+nloc) of a
+ * global problem of ncrms_global instances. dist: 1 conditioned, 2 raw
+ * U[0,1), 3 raw with signed u,w. */
+int mpdata_fill_synthetic_device(double* a, int sid, int64_t rows, int64_t ncrms_global,
+                                 int64_t sl0, int64_t nloc, uint64_t seed, int dist,
+                                 void* stream);
+
+/* ---- 5. Shard pack/unpack for the multi-GPU scatter/gather (device
+ * pointers).  A shard [sl0, sl0+nloc) of an array with leading dimension
+ * ncrms is a strided slab; pack makes it contiguous (leading dimension
+ * nloc), unpack writes it back. */
+int mpdata_pack_shard_device(const double* full, double* shard, int64_t rows, int64_t ncrms,
+                             int64_t sl0, int64_t nloc, void* stream);
+int mpdata_unpack_shard_device(double* full, const double* shard, int64_t rows, int64_t ncrms,
+                               int64_t sl0, int64_t nloc, void* stream);
+
+/* ---- 6. Misc. */
+int mpdata_set_variant(int variant);      /* MPDATA_VARIANT_*; returns previous */
+int mpdata_get_variant(void);
+int mpdata_set_tile(int tile);            /* kernel tiling id; -1 = default */
+int mpdata_device_count(void);
+int64_t mpdata_algorithmic_bytes(int64_t ncrms, int nx, int nz, int ntracers);
+const char* mpdata_last_error(void);
+const char* mpdata_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPDATA_HIP_H */

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""oracle/build_ref.py -- TEST INFRASTRUCTURE: build the reference itself.
+
+Compiles the reference Fortran program
+  /root/reference/mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90
+from the source where it lies, into per-shape executables under oracle/_ref/
+(git-ignored; only binaries ever land there).  The reference is a `program`
+with compile-time sizes (:7-9), compiler-RNG inputs (:654-660) and no output
+of field values, so three line-anchored edits are applied IN MEMORY to a
+scratch copy that lives in a mkdtemp() directory and is deleted after the
+compile -- no reference source text is written into this repository:
+
+  1. :7-9    nslices / nz / nx            -> the requested shape
+  2. :654-660 call random_number(X) x7     -> stream-binary reads of X from
+                                              ./mpdata_in.bin (same order:
+                                              adz,f,u,w,rho,rhow,flux)
+  3. after :49 (call advect_scalar2D_cpu)  -> stream-binary dump of f, flux
+                                              to ./mpdata_out.bin
+
+The arithmetic body (:477-642) is untouched.  Flags: `amdflang -O3
+-ffp-contract=off` (flang does not re-associate; -O0 and -O3 agree bitwise,
+SURVEY.md section 8c).  The executable still prints the reference's own
+`CPU Timing:` line (:640), which bench.py's cpu_baseline leg parses.
+
+Usage:  python oracle/build_ref.py NCRMS NX NZ [NCRMS NX NZ ...]
+Needs /root/reference and amdflang; on the GPU box neither is used -- the
+prebuilt oracle/_ref binaries travel with the snapshot.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SRC = "/root/reference/mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90"
+OUT_DIR = os.path.join(HERE, "_ref")
+FC = shutil.which("amdflang") or "/opt/rocm/bin/amdflang"
+
+
+def ref_exe_path(ncrms, nx, nz):
+    return os.path.join(OUT_DIR, f"advect_ref_{ncrms}x{nx}x{nz}")
+
+
+def _patched_lines(ncrms, nx, nz):
+    with open(REF_SRC) as fh:
+        lines = fh.read().split("\n")
+
+    def expect(lineno, pattern):
+        if not re.search(pattern, lines[lineno - 1]):
+            raise RuntimeError(f"reference line {lineno} is not what build_ref.py expects: "
+                               f"{lines[lineno - 1]!r}")
+
+    # 1. sizes (:7-9)
+    expect(7, r"parameter\s*::\s*nslices\s*=")
+    expect(8, r"parameter\s*::\s*nz\s*=")
+    expect(9, r"parameter\s*::\s*nx\s*=")
+    lines[6] = f"  integer, parameter :: nslices = {ncrms}"
+    lines[7] = f"  integer, parameter :: nz      = {nz}"
+    lines[8] = f"  integer, parameter :: nx      = {nx}"
+    # 2. inputs (:654-660): same arrays, same order, read instead of drawn
+    names = ["adz", "f", "u", "w", "rho", "rhow", "flux"]
+    for off, name in enumerate(names):
+        expect(654 + off, rf"call random_number\({name}\s*\)")
+        lines[653 + off] = f"    read(91) {name}"
+    lines[653] = ("    open(unit=91, file='mpdata_in.bin', access='stream', form='unformatted', "
+                  "status='old')\n" + lines[653])
+    lines[659] = lines[659] + "\n    close(91)"
+    # 3. outputs: dump after the CPU call (:49)
+    expect(49, r"call advect_scalar2D_cpu\(f,u,w,rho,rhow,flux\)")
+    lines[48] = (lines[48] + "\n"
+                 "  open(unit=92, file='mpdata_out.bin', access='stream', form='unformatted', "
+                 "status='replace')\n"
+                 "  write(92) f\n  write(92) flux\n  close(92)")
+    return "\n".join(lines)
+
+
+def build(ncrms, nx, nz, force=False):
+    """Build oracle/_ref/advect_ref_<shape>; returns its path."""
+    exe = ref_exe_path(ncrms, nx, nz)
+    if os.path.exists(exe) and not force:
+        return exe
+    if not os.path.exists(REF_SRC):
+        raise FileNotFoundError(f"{REF_SRC} not present (the reference does not travel); "
+                                "use the prebuilt binary")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="mpdata_ref_")
+    try:
+        src = os.path.join(tmp, "ref_patched.F90")
+        with open(src, "w") as fh:
+            fh.write(_patched_lines(ncrms, nx, nz))
+        flags = ["-O3", "-ffp-contract=off"]
+        # statics (f,u,w + their _save copies) beyond 2 GB need the medium model
+        static_bytes = 2 * 8 * ncrms * ((nx + 6) + (nx + 5)) * (nz - 1) + 2 * 8 * ncrms * (nx + 4) * nz
+        if static_bytes > 1.5e9:
+            flags.append("-mcmodel=medium")
+        subprocess.run([FC, *flags, "-o", exe, src], check=True, cwd=tmp)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return exe
+
+
+if __name__ == "__main__":
+    args = [int(a) for a in sys.argv[1:]]
+    if not args or len(args) % 3:
+        sys.exit(__doc__)
+    for j in range(0, len(args), 3):
+        print(build(*args[j:j + 3], force=True))

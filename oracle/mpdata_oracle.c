@@ -1,0 +1,316 @@
+/*
+ * oracle/mpdata_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, fp64) of the E3SM-MMF 2D MPDATA tracer advection
+ * routine of the reference:
+ *   mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:477-642
+ *   (subroutine advect_scalar2D_cpu; constants/statement functions :500-510).
+ * It is the parity checker for the HIP path and the "port" CPU baseline.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it;
+ * the product library (libmpdata_hip.so) never links or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this file
+ * bit-for-bit against outputs of the reference Fortran itself (compiled here
+ * by oracle/build_ref.py with `amdflang -O3 -ffp-contract=off`), committed as
+ * fixtures under tests/golden/.  Build with -ffp-contract=off: every
+ * expression below keeps the reference's evaluation order, and the only
+ * legal difference between two IEEE builds of the reference is FMA
+ * contraction.
+ *
+ * Array layout = the reference's Fortran column-major declarations
+ * (reference :479-491), `sl` (CRM instance, "nslices"/ncrms) fastest:
+ *   f   (ncrms, -2:nx+3, 1, nzm)   inout
+ *   u   (ncrms, -1:nx+3, 1, nzm)   in
+ *   w   (ncrms, -1:nx+2, 1, nz )   in
+ *   rho (ncrms, nzm) in;  rhow(ncrms, nz) in;  adz(ncrms, nzm) in (host-
+ *   associated global in the reference, :30);  flux(ncrms, nz) out.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+  int64_t n;      /* ncrms (leading dimension of every array) */
+  int nx, nz, nzm;
+} dims_t;
+
+/* Fortran-style indexers (1-based k, signed i), sl is 0-based here. */
+#define F_(sl, i, k)   f  [(sl) + d.n * ((int64_t)((i) + 2) + (int64_t)(d.nx + 6) * ((k) - 1))]
+#define U_(sl, i, k)   u  [(sl) + d.n * ((int64_t)((i) + 1) + (int64_t)(d.nx + 5) * ((k) - 1))]
+#define W_(sl, i, k)   w  [(sl) + d.n * ((int64_t)((i) + 1) + (int64_t)(d.nx + 4) * ((k) - 1))]
+#define MX_(sl, i, k)  mx [(sl) + d.n * ((int64_t)(i)       + (int64_t)(d.nx + 2) * ((k) - 1))]
+#define MN_(sl, i, k)  mn [(sl) + d.n * ((int64_t)(i)       + (int64_t)(d.nx + 2) * ((k) - 1))]
+#define UUU_(sl, i, k) uuu[(sl) + d.n * ((int64_t)((i) + 1) + (int64_t)(d.nx + 5) * ((k) - 1))]
+#define WWW_(sl, i, k) www[(sl) + d.n * ((int64_t)((i) + 1) + (int64_t)(d.nx + 4) * ((k) - 1))]
+#define K2_(a, sl, k)  a  [(sl) + d.n * (int64_t)((k) - 1)]
+
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+static inline double dmin(double a, double b) { return a < b ? a : b; }
+/* Statement functions, reference :500-503 (left-to-right association). */
+static inline double andiff(double x1, double x2, double a, double b) {
+  return (fabs(a) - a * a * b) * 0.5 * (x2 - x1);
+}
+static inline double across(double x1, double a1, double a2) {
+  return 0.03125 * a1 * a2 * x1;
+}
+static inline double pp(double y) { return dmax(0.0, y); }
+static inline double pn(double y) { return -dmin(0.0, y); }
+
+/* Scratch = the reference's automatic arrays (:485-491), heap allocated. */
+typedef struct {
+  double *mx, *mn, *uuu, *www, *iadz, *irho, *irhow;
+} scratch_t;
+
+static int scratch_alloc(scratch_t *s, dims_t d) {
+  size_t n = (size_t)d.n;
+  s->mx = (double *)malloc(n * (d.nx + 2) * d.nzm * sizeof(double));
+  s->mn = (double *)malloc(n * (d.nx + 2) * d.nzm * sizeof(double));
+  s->uuu = (double *)malloc(n * (d.nx + 5) * d.nzm * sizeof(double));
+  s->www = (double *)malloc(n * (d.nx + 4) * d.nz * sizeof(double));
+  s->iadz = (double *)malloc(n * d.nzm * sizeof(double));
+  s->irho = (double *)malloc(n * d.nzm * sizeof(double));
+  s->irhow = (double *)malloc(n * d.nzm * sizeof(double));
+  return (s->mx && s->mn && s->uuu && s->www && s->iadz && s->irho && s->irhow) ? 0 : -1;
+}
+static void scratch_free(scratch_t *s) {
+  free(s->mx); free(s->mn); free(s->uuu); free(s->www);
+  free(s->iadz); free(s->irho); free(s->irhow);
+}
+
+/*
+ * The reference body, restricted to CRM instances sl in [s0, s1).  No
+ * statement of the reference couples different sl, so running it per
+ * sl-range is the same arithmetic in the same order for every element.
+ */
+static void advect_range(dims_t d, int64_t s0, int64_t s1, double *f, const double *u,
+                         const double *w, const double *rho, const double *rhow,
+                         const double *adz, double *flux, scratch_t sc) {
+  double *mx = sc.mx, *mn = sc.mn, *uuu = sc.uuu, *www = sc.www;
+  double *iadz = sc.iadz, *irho = sc.irho, *irhow = sc.irhow;
+  const int nx = d.nx, nz = d.nz, nzm = d.nzm;
+  const int nxp1 = nx + 1, nxp2 = nx + 2, nxp3 = nx + 3;
+  /* reference :509 -- `eps = 1.e-10` is a default-real (fp32) literal
+   * assigned to an fp64 variable. */
+  const double eps = (double)1.e-10f;
+  int i, k, kc, kb, ib, ic;
+  int64_t sl;
+
+  /* :511  www(:,:,:,nz)=0. */
+  for (i = -1; i <= nxp2; i++)
+    for (sl = s0; sl < s1; sl++) WWW_(sl, i, nz) = 0.0;
+
+  /* :513-526  pass-0 extrema (nonos is hard-wired .true., :508) */
+  for (k = 1; k <= nzm; k++) {
+    kc = k + 1 < nzm ? k + 1 : nzm;
+    kb = k - 1 > 1 ? k - 1 : 1;
+    for (i = 0; i <= nxp1; i++)
+      for (sl = s0; sl < s1; sl++) {
+        ib = i - 1; ic = i + 1;
+        MX_(sl, i, k) = dmax(dmax(dmax(dmax(F_(sl, ib, k), F_(sl, ic, k)), F_(sl, i, kb)), F_(sl, i, kc)), F_(sl, i, k));
+        MN_(sl, i, k) = dmin(dmin(dmin(dmin(F_(sl, ib, k), F_(sl, ic, k)), F_(sl, i, kb)), F_(sl, i, kc)), F_(sl, i, k));
+      }
+  }
+
+  /* :528-548  upwind fluxes and their horizontal sum */
+  for (k = 1; k <= nzm; k++) {
+    kb = k - 1 > 1 ? k - 1 : 1;
+    for (i = -1; i <= nxp3; i++)
+      for (sl = s0; sl < s1; sl++)
+        UUU_(sl, i, k) = dmax(0.0, U_(sl, i, k)) * F_(sl, i - 1, k) + dmin(0.0, U_(sl, i, k)) * F_(sl, i, k);
+    for (i = -1; i <= nxp2; i++)
+      for (sl = s0; sl < s1; sl++)
+        WWW_(sl, i, k) = dmax(0.0, W_(sl, i, k)) * F_(sl, i, kb) + dmin(0.0, W_(sl, i, k)) * F_(sl, i, k);
+    for (sl = s0; sl < s1; sl++) K2_(flux, sl, k) = 0.0;
+    for (i = 1; i <= nx; i++)
+      for (sl = s0; sl < s1; sl++) K2_(flux, sl, k) = K2_(flux, sl, k) + WWW_(sl, i, k);
+  }
+
+  /* :550-560  first-pass update, halo columns -1..nx+2 included */
+  for (k = 1; k <= nzm; k++) {
+    for (sl = s0; sl < s1; sl++) {
+      K2_(irho, sl, k) = 1.0 / K2_(rho, sl, k);
+      K2_(iadz, sl, k) = 1.0 / K2_(adz, sl, k);
+    }
+    for (i = -1; i <= nxp2; i++)
+      for (sl = s0; sl < s1; sl++)
+        F_(sl, i, k) = F_(sl, i, k) - (UUU_(sl, i + 1, k) - UUU_(sl, i, k) +
+                                       (WWW_(sl, i, k + 1) - WWW_(sl, i, k)) * K2_(iadz, sl, k)) * K2_(irho, sl, k);
+  }
+
+  /* :561-586  antidiffusive fluxes */
+  for (k = 1; k <= nzm; k++) {
+    kc = k + 1 < nzm ? k + 1 : nzm;
+    kb = k - 1 > 1 ? k - 1 : 1;
+    /* :569  `2./(kc-kb)` is default-real / integer: exactly 1.0 or 2.0 */
+    const double two_over = (double)(2.0f / (float)(kc - kb));
+    for (sl = s0; sl < s1; sl++) K2_(irhow, sl, k) = 1.0 / (K2_(rhow, sl, k) * K2_(adz, sl, k));
+    for (i = 0; i <= nxp2; i++)
+      for (sl = s0; sl < s1; sl++) {
+        const double dd = two_over / K2_(adz, sl, k);
+        ib = i - 1;
+        UUU_(sl, i, k) = andiff(F_(sl, ib, k), F_(sl, i, k), U_(sl, i, k), K2_(irho, sl, k)) -
+                         across(dd * (F_(sl, ib, kc) + F_(sl, i, kc) - F_(sl, ib, kb) - F_(sl, i, kb)),
+                                U_(sl, i, k),
+                                W_(sl, ib, k) + W_(sl, ib, kc) + W_(sl, i, k) + W_(sl, i, kc)) * K2_(irho, sl, k);
+      }
+    for (i = 0; i <= nxp1; i++)
+      for (sl = s0; sl < s1; sl++) {
+        ib = i - 1; ic = i + 1;
+        WWW_(sl, i, k) = andiff(F_(sl, i, kb), F_(sl, i, k), W_(sl, i, k), K2_(irhow, sl, k)) -
+                         across(F_(sl, ic, kb) + F_(sl, ic, k) - F_(sl, ib, kb) - F_(sl, ib, k),
+                                W_(sl, i, k),
+                                U_(sl, i, kb) + U_(sl, i, k) + U_(sl, ic, k) + U_(sl, ic, kb)) * K2_(irho, sl, k);
+      }
+  }
+  /* :586  www(:,:,:,1) = 0. */
+  for (i = -1; i <= nxp2; i++)
+    for (sl = s0; sl < s1; sl++) WWW_(sl, i, 1) = 0.0;
+
+  /* :588-600  pass-1 extrema */
+  for (k = 1; k <= nzm; k++) {
+    kc = k + 1 < nzm ? k + 1 : nzm;
+    kb = k - 1 > 1 ? k - 1 : 1;
+    for (i = 0; i <= nxp1; i++)
+      for (sl = s0; sl < s1; sl++) {
+        ib = i - 1; ic = i + 1;
+        MX_(sl, i, k) = dmax(dmax(dmax(dmax(dmax(F_(sl, ib, k), F_(sl, ic, k)), F_(sl, i, kb)), F_(sl, i, kc)), F_(sl, i, k)), MX_(sl, i, k));
+        MN_(sl, i, k) = dmin(dmin(dmin(dmin(dmin(F_(sl, ib, k), F_(sl, ic, k)), F_(sl, i, kb)), F_(sl, i, kc)), F_(sl, i, k)), MN_(sl, i, k));
+      }
+  }
+  /* :601-612  limiter normalisation (note kc clamps at nzm, :602) */
+  for (k = 1; k <= nzm; k++) {
+    kc = k + 1 < nzm ? k + 1 : nzm;
+    for (i = 0; i <= nxp1; i++)
+      for (sl = s0; sl < s1; sl++) {
+        ic = i + 1;
+        MX_(sl, i, k) = K2_(rho, sl, k) * (MX_(sl, i, k) - F_(sl, i, k)) /
+                        (pn(UUU_(sl, ic, k)) + pp(UUU_(sl, i, k)) +
+                         K2_(iadz, sl, k) * (pn(WWW_(sl, i, kc)) + pp(WWW_(sl, i, k))) + eps);
+        MN_(sl, i, k) = K2_(rho, sl, k) * (F_(sl, i, k) - MN_(sl, i, k)) /
+                        (pp(UUU_(sl, ic, k)) + pn(UUU_(sl, i, k)) +
+                         K2_(iadz, sl, k) * (pp(WWW_(sl, i, kc)) + pn(WWW_(sl, i, k))) + eps);
+      }
+  }
+  /* :613-627  flux limiting; flux gets the limited vertical flux added */
+  for (k = 1; k <= nzm; k++) {
+    kb = k - 1 > 1 ? k - 1 : 1;
+    for (i = 1; i <= nxp1; i++)
+      for (sl = s0; sl < s1; sl++) {
+        ib = i - 1;
+        UUU_(sl, i, k) = pp(UUU_(sl, i, k)) * dmin(dmin(1.0, MX_(sl, i, k)), MN_(sl, ib, k)) -
+                         pn(UUU_(sl, i, k)) * dmin(dmin(1.0, MX_(sl, ib, k)), MN_(sl, i, k));
+      }
+    for (i = 1; i <= nx; i++)
+      for (sl = s0; sl < s1; sl++) {
+        WWW_(sl, i, k) = pp(WWW_(sl, i, k)) * dmin(dmin(1.0, MX_(sl, i, k)), MN_(sl, i, kb)) -
+                         pn(WWW_(sl, i, k)) * dmin(dmin(1.0, MX_(sl, i, kb)), MN_(sl, i, k));
+        K2_(flux, sl, k) = K2_(flux, sl, k) + WWW_(sl, i, k);
+      }
+  }
+
+  /* :630-637  final positive-definite update of the interior */
+  for (k = 1; k <= nzm; k++)
+    for (i = 1; i <= nx; i++)
+      for (sl = s0; sl < s1; sl++)
+        F_(sl, i, k) = dmax(0.0, F_(sl, i, k) - (UUU_(sl, i + 1, k) - UUU_(sl, i, k) +
+                                                 (WWW_(sl, i, k + 1) - WWW_(sl, i, k)) * K2_(iadz, sl, k)) * K2_(irho, sl, k));
+}
+
+/*
+ * One call of advect_scalar2D_cpu(f,u,w,rho,rhow,flux) (reference :477) on
+ * runtime sizes.  `nthreads` <= 1: one serial pass over all sl, exactly the
+ * reference's loop structure.  `nthreads` > 1: OpenMP over contiguous
+ * sl-chunks (this build's own addition; the reference is serial), same
+ * arithmetic per element.  Returns 0, or -1 on bad sizes / allocation failure.
+ */
+int mpdata_oracle_advect(int64_t ncrms, int nx, int nz, double *f, const double *u,
+                         const double *w, const double *rho, const double *rhow,
+                         const double *adz, double *flux, int nthreads) {
+  dims_t d;
+  scratch_t sc;
+  if (ncrms < 1 || nx < 1 || nz < 3) return -1;
+  d.n = ncrms; d.nx = nx; d.nz = nz; d.nzm = nz - 1;
+  if (scratch_alloc(&sc, d) != 0) { scratch_free(&sc); return -1; }
+  if (nthreads <= 1) {
+    advect_range(d, 0, ncrms, f, u, w, rho, rhow, adz, flux, sc);
+  } else {
+    const int64_t chunk = 64;
+    const int64_t nchunks = (ncrms + chunk - 1) / chunk;
+    int64_t c;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+    for (c = 0; c < nchunks; c++) {
+      int64_t s0 = c * chunk, s1 = s0 + chunk < ncrms ? s0 + chunk : ncrms;
+      advect_range(d, s0, s1, f, u, w, rho, rhow, adz, flux, sc);
+    }
+  }
+  scratch_free(&sc);
+  return 0;
+}
+
+/* Tracer-batched semantics (not in the reference): the result
+ * of calling the routine once per tracer with the same u,w,rho,rhow,adz.
+ * f(ncrms,-2:nx+3,1,nzm,ntracers), flux(ncrms,nz,ntracers). */
+int mpdata_oracle_advect_tracers(int64_t ncrms, int nx, int nz, int ntracers, double *f,
+                                 const double *u, const double *w, const double *rho,
+                                 const double *rhow, const double *adz, double *flux,
+                                 int nthreads) {
+  int t, rc = 0;
+  const int64_t fstride = ncrms * (int64_t)(nx + 6) * (nz - 1);
+  const int64_t xstride = ncrms * (int64_t)nz;
+  if (ntracers < 1) return -1;
+  for (t = 0; t < ntracers && rc == 0; t++)
+    rc = mpdata_oracle_advect(ncrms, nx, nz, f + t * fstride, u, w, rho, rhow, adz,
+                              flux + t * xstride, nthreads);
+  return rc;
+}
+
+int mpdata_oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/*
+ * Synthetic inputs (this build's own generator; the reference uses the
+ * compiler's random_number, :649-660, which is not reproducible across
+ * compilers).  Counter-based splitmix64: element j (0-based global linear
+ * index in the reference's array order) of array `sid` (0..6 = adz,f,u,w,
+ * rho,rhow,flux -- the reference's fill order :654-660) is
+ *   r = top53(mix(seed + sid*K + (j+1)*GOLDEN)) * 2^-53  in [0,1)
+ * dist 1 "conditioned": f,flux = r; u,w = r-0.5; rho,rhow,adz = r+0.5
+ * dist 2 "reference-raw": everything r (what :654-660 produces in law)
+ * dist 3 "raw-signed": as 2 but u,w = r-0.5
+ * A shard [sl0, sl0+nloc) of a global ncrms is generated with the GLOBAL
+ * index, so shards of any partition reproduce the unsharded data.
+ */
+static inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+void mpdata_oracle_fill(double *a, int sid, int64_t rows, int64_t ncrms_global, int64_t sl0,
+                        int64_t nloc, uint64_t seed, int dist) {
+  const uint64_t base = seed + (uint64_t)sid * 0xD1B54A32D192ED03ull;
+  double shift = 0.0;
+  int64_t r, s;
+  if (dist == 1) {
+    if (sid == 2 || sid == 3) shift = -0.5;
+    else if (sid == 0 || sid == 4 || sid == 5) shift = 0.5;
+  } else if (dist == 3) {
+    if (sid == 2 || sid == 3) shift = -0.5;
+  }
+  for (r = 0; r < rows; r++)
+    for (s = 0; s < nloc; s++) {
+      uint64_t j = (uint64_t)(r * ncrms_global + sl0 + s);
+      uint64_t z = mix64(base + (j + 1) * 0x9E3779B97F4A7C15ull);
+      a[r * nloc + s] = (double)(z >> 11) * 0x1.0p-53 + shift;
+    }
+}

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""tests/golden/make_golden.py -- regenerate the golden vectors.
+
+Each fixture is the OUTPUT (f, flux) of the reference Fortran program itself
+(built from /root/reference by oracle/build_ref.py, `amdflang -O3
+-ffp-contract=off`) on inputs produced by this repo's seeded generator
+(oracle/oracle.py:make_inputs).  Inputs are not stored: they are regenerated
+from (shape, seed, dist).  Only data is committed (npz + manifest.json); no
+reference source text.  Runs in the build container only (needs
+/root/reference + amdflang).
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import build_ref  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+# (ncrms, nx, nz, seed, dist)
+CASES = [
+    (3, 8, 6, 100, O.DIST_CONDITIONED),
+    (3, 8, 6, 100, O.DIST_RAW),
+    (3, 8, 6, 100, O.DIST_RAW_SIGNED),
+    (8, 32, 28, 100, O.DIST_CONDITIONED),
+    (8, 32, 28, 7, O.DIST_RAW_SIGNED),
+    (64, 32, 28, 100, O.DIST_CONDITIONED),   # BASELINE.json configs[0]
+    (64, 32, 28, 100, O.DIST_RAW),           # ... with the reference's U[0,1) law
+    (48, 32, 58, 100, O.DIST_RAW),           # the reference's shipped size (:7-9)
+]
+
+
+def case_name(ncrms, nx, nz, seed, dist):
+    return f"ref_{ncrms}x{nx}x{nz}_seed{seed}_dist{dist}"
+
+
+def main():
+    manifest = {"generator": "tests/golden/make_golden.py",
+                "reference": "mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90 "
+                             "(advect_scalar2D_cpu, :477-642)",
+                "compiler": "amdflang -O3 -ffp-contract=off",
+                "cases": []}
+    for (ncrms, nx, nz, seed, dist) in CASES:
+        build_ref.build(ncrms, nx, nz)
+        inp = O.make_inputs(ncrms, nx, nz, seed=seed, dist=dist)
+        f, flux, _ = O.run_reference(inp)
+        name = case_name(ncrms, nx, nz, seed, dist)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez(path, f=f, flux=flux)
+        manifest["cases"].append({
+            "name": name, "ncrms": ncrms, "nx": nx, "nz": nz, "seed": seed, "dist": dist,
+            "f_sha256": hashlib.sha256(f.tobytes(order="F")).hexdigest(),
+            "flux_sha256": hashlib.sha256(flux.tobytes(order="F")).hexdigest(),
+            "inputs_sha256": hashlib.sha256(b"".join(
+                inp[k].tobytes(order="F") for k in ("adz", "f", "u", "w", "rho", "rhow", "flux")
+            )).hexdigest(),
+            "f_min": float(f.min()), "f_max": float(f.max()),
+        })
+        print(name, f.shape, flux.shape)
+    with open(os.path.join(HERE, "manifest.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

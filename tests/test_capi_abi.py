@@ -1,0 +1,76 @@
+"""CPU tests of the drop-in boundary: libmpdata_hip.so loads without a GPU,
+exports every symbol include/mpdata_hip.h declares, and rejects bad arguments
+before touching the device.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mpdata_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpdata_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    for s in ("mpdata_advect_scalar2d", "mpdata_advect_scalar2d_device", "mpdata_plan_create",
+              "mpdata_plan_upload", "mpdata_plan_run", "mpdata_plan_sync", "mpdata_plan_download",
+              "mpdata_plan_destroy", "mpdata_last_error"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(mpdata):
+    L = ctypes.CDLL(mpdata.lib_path())
+    for s in declared_symbols():
+        assert hasattr(L, s), f"{s} declared in include/mpdata_hip.h but not exported"
+
+
+def test_argument_errors_without_device(mpdata):
+    L = mpdata.lib()
+    one = ctypes.c_void_p(8)  # never dereferenced: validation comes first
+    # nz < 3 (reference needs kc != kb, :569), ncrms < 1, nx < 1, ntracers < 1
+    for (n, nx, nz, nt) in ((4, 8, 2, 1), (0, 8, 6, 1), (4, 0, 6, 1), (4, 8, 6, 0)):
+        rc = L.mpdata_advect_scalar2d_device(n, nx, nz, nt, one, one, one, one, one, one, one, None)
+        assert rc == -1, (n, nx, nz, nt)
+        assert b"bad sizes" in L.mpdata_last_error()
+    rc = L.mpdata_advect_scalar2d_device(4, 8, 6, 1, None, one, one, one, one, one, one, None)
+    assert rc == -1
+    # wider than any tiling -> MPDATA_EUNSUPPORTED
+    rc = L.mpdata_advect_scalar2d_device(4, 4000, 6, 1, one, one, one, one, one, one, one, None)
+    assert rc == -2
+    p = ctypes.c_void_p()
+    assert L.mpdata_plan_create(4, 8, 2, 1, ctypes.byref(p)) == -1 and not p.value
+
+
+def test_algorithmic_bytes_formula(mpdata):
+    # B1 = 8*nzm*(4nx+23) per CRM; BT = 8*nzm*(T(2nx+11)+2nx+12)
+    assert mpdata.algorithmic_bytes(1, 32, 28, 1) == 32616
+    assert mpdata.algorithmic_bytes(1, 32, 28, 25) == 421416
+    assert mpdata.algorithmic_bytes(65536, 32, 28, 1) == 65536 * 32616
+
+
+def test_variant_switch(mpdata):
+    prev = mpdata.set_variant(mpdata.VARIANT_FAST)
+    assert mpdata.get_variant() == mpdata.VARIANT_FAST
+    mpdata.set_variant(mpdata.VARIANT_EXACT)
+    assert mpdata.get_variant() == mpdata.VARIANT_EXACT
+    mpdata.set_variant(prev)
+
+
+def test_no_cpu_fallback_in_product(mpdata):
+    """The product library must not link or reference anything under oracle/."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", mpdata.lib_path()], capture_output=True, text=True).stdout
+    assert "mpdata_oracle" not in out
+    pkg = os.path.join(ROOT, "codesign-kernels_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".F90", ".f90")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in src and "from oracle" not in src, fn
+                assert "libmpdata_oracle" not in src, fn
