@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- MPDATA tracer-advection throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one call of advect_scalar2D (the fused HIP kernel) over one batch
+of synthetic input that is already resident in HBM: BASELINE.json configs[2]
+per GPU -- ncrms=65536, nx=32, nz=28, fp64, 1 tracer.  The ncrms axis is
+embarrassingly parallel, so N GPUs run N shards of a global ncrms=N*65536
+problem with no data-path collective (weak scaling); RCCL is only used for the
+barrier / max-over-ranks of the timing (and, outside the timed region, by the
+optional --scatter check).  Every step works on its own pristine copy of f
+(the routine updates f in place), so no restore sits inside the timed region.
+
+Prints ONE JSON line (rank 0).  `value` = cell-updates/s of the whole job;
+`roofline` = algorithmic HBM bytes per launch / mean kernel time (HIP events
+on the launch stream) against the 8 TB/s HBM3E peak; `cpu_baseline` = the
+reference Fortran executable itself (oracle/_ref, built from /root/reference
+by oracle/build_ref.py) timed on this box's host, 1 core, ncrms=4096.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ncrms-per-gpu", type=int, default=65536)
+    ap.add_argument("--nx", type=int, default=32)
+    ap.add_argument("--nz", type=int, default=28)
+    ap.add_argument("--tracers", type=int, default=1)
+    ap.add_argument("--variant", choices=["exact", "fast"], default=os.environ.get("MPDATA_VARIANT", "exact"))
+    ap.add_argument("--tile", type=int, default=-1)
+    ap.add_argument("--dist", type=int, default=1, help="1 conditioned, 2 reference-raw, 3 raw-signed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the 25-tracer side measurement")
+    ap.add_argument("--batched-tracers", type=int, default=25)
+    ap.add_argument("--scatter", action="store_true",
+                    help="also time the RCCL scatter/gather of a small problem (outside the timed region)")
+    return ap.parse_args()
+
+
+def cpu_baseline(nx, nz):
+    """The reference program itself on the host (1 core; the reference is
+    serial, mmf-mpdata-tracer/Makefile has no OpenMP).  Bounded sample:
+    ncrms=4096, repeated runs, ~10-20 s."""
+    from oracle import oracle as O
+    ncrms = 4096
+    cells = ncrms * nx * (nz - 1)
+    inp = O.make_inputs(ncrms, nx, nz, seed=100, dist=O.DIST_CONDITIONED)
+    out = {}
+    if O.ref_exe(ncrms, nx, nz) is not None:
+        times = []
+        t_end = time.time() + 15.0
+        while len(times) < 12 and (time.time() < t_end or len(times) < 3):
+            _, _, t = O.run_reference(inp, want_outputs=False)
+            times.append(t)
+        t = statistics.median(times)
+        out = {"value": cells / t, "unit": "cell-updates/s", "cores": 1, "kind": "reference",
+               "sample": f"reference executable (amdflang -O3 -ffp-contract=off), ncrms={ncrms} nx={nx} "
+                         f"nz={nz}, median of {len(times)} cold single calls (its own 'CPU Timing' line)",
+               "seconds_per_call": t}
+    # the C restatement, serial and on all host cores (this build's own OpenMP)
+    O.build_lib()
+    reps = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.advect(inp, nthreads=1)
+        reps.append(time.perf_counter() - t0)
+    port1 = cells / min(reps)
+    nthr = O.max_threads()
+    reps = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.advect(inp, nthreads=nthr)
+        reps.append(time.perf_counter() - t0)
+    portn = cells / min(reps)
+    if not out:
+        out = {"value": port1, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+               "sample": f"C restatement (gcc -O3 -ffp-contract=off), ncrms={ncrms}, best of 3"}
+    out["port_serial"] = port1
+    out["port_openmp"] = {"value": portn, "cores": nthr}
+    return out
+
+
+def make_problem(M, torch, dev, ncrms_loc, ncrms_glob, sl0, nx, nz, ntr, nbuf, dist):
+    sh = M.shapes(ncrms_loc, nx, nz, ntr)
+    d = {k: torch.empty(sh[k], dtype=torch.float64, device=dev) for k in ("u", "w", "rho", "rhow", "adz", "flux")}
+    for k in d:
+        M.fill_synthetic(d[k], k, 100, dist, ncrms_global=ncrms_glob, sl0=sl0)
+    fs = []
+    for b in range(nbuf):
+        f = torch.empty(sh["f"], dtype=torch.float64, device=dev)
+        # per-tracer / per-buffer seeds: distinct data, same law
+        if ntr == 1:
+            M.fill_synthetic(f, "f", 100 + b, dist, ncrms_global=ncrms_glob, sl0=sl0)
+        else:
+            for t in range(ntr):
+                M.fill_synthetic(f[t], "f", 100 + b * ntr + t, dist, ncrms_global=ncrms_glob, sl0=sl0)
+        fs.append(f)
+    return d, fs
+
+
+def timed_run(M, torch, dist_mod, world, d, fs, steps, warmup):
+    def step(f):
+        M.advect_scalar2D(f, d["u"], d["w"], d["rho"], d["rhow"], d["flux"], d["adz"])
+
+    for i in range(warmup):
+        step(fs[i])
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        step(fs[warmup + i])
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms = [a.elapsed_time(b) for a, b in ev]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, kms
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import codesign_kernels_amd as M
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    M.set_variant(M.VARIANT_FAST if args.variant == "fast" else M.VARIANT_EXACT)
+    M.set_tile(args.tile)
+    nx, nz = args.nx, args.nz
+    n_loc = args.ncrms_per_gpu
+    n_glob = n_loc * world
+    sl0 = rank * n_loc
+    steps, warmup = args.steps, args.warmup
+
+    # ---- headline: 1 tracer (or --tracers) ---------------------------------
+    ntr = args.tracers
+    d, fs = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, ntr, steps + warmup, args.dist)
+    dt, kms = timed_run(M, torch, dist, world, d, fs, steps, warmup)
+    cells_per_step = n_glob * nx * (nz - 1) * ntr
+    value = cells_per_step * steps / dt
+    alg_bytes = M.algorithmic_bytes(n_loc, nx, nz, ntr)  # per launch (one GPU)
+    k_avg = sum(kms) / len(kms)
+    achieved = alg_bytes / (k_avg * 1e-3) / 1e9
+    del fs
+    torch.cuda.empty_cache()
+
+    result = None
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t{ntr}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "advected cell-updates/sec, MPDATA advect_scalar2D (ncrms=65536 per GPU, nx=32, nz=28)",
+            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[2]: ncrms={n_loc}/GPU (global {n_glob}) nx={nx} "
+                                   f"nz={nz} fp64 tracers={ntr}, device-resident, in-place f",
+                       "ncrms_per_gpu": n_loc, "ncrms_global": n_glob, "nx": nx, "nz": nz,
+                       "ntracers": ntr, "variant": args.variant, "input_law": args.dist,
+                       "parallelism": f"ncrms-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms_avg": k_avg, "kernel_ms_min": min(kms),
+                         "kernel_ms_median": statistics.median(kms),
+                         "cell_updates_per_sec_kernel": n_loc * nx * (nz - 1) * ntr / (k_avg * 1e-3)},
+        }
+
+    # ---- side measurement: tracer-batched variant (configs[3]/[4]) -----------
+    if not args.no_batched and ntr == 1:
+        bt = args.batched_tracers
+        bsteps, bwarm = min(steps, 5), 1
+        d2, fs2 = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, bt, bsteps + bwarm, args.dist)
+        dt2, kms2 = timed_run(M, torch, dist, world, d2, fs2, bsteps, bwarm)
+        if rank == 0:
+            ab = M.algorithmic_bytes(n_loc, nx, nz, bt)
+            ka = sum(kms2) / len(kms2)
+            result["tracer_batched"] = {
+                "workload": f"BASELINE.json configs[3]: ncrms={n_loc}/GPU, {bt} tracers sharing u,w,rho,rhow,adz",
+                "value": n_glob * nx * (nz - 1) * bt * bsteps / dt2, "unit": "cell-updates/s",
+                "steps": bsteps, "ms_per_step": dt2 / bsteps * 1e3,
+                "roofline": {"bound": "hbm", "achieved": ab / (ka * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": ab / (ka * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": ab, "kernel_ms_avg": ka}}
+        del fs2, d2
+        torch.cuda.empty_cache()
+
+    # ---- optional: scatter/gather over RCCL (outside any timed region) ------
+    if args.scatter and world > 1:
+        ns = 4096 * world
+        names = ("adz", "f", "u", "w", "rho", "rhow", "flux")
+        sh = M.shapes(ns, nx, nz)
+        if rank == 0:
+            full = {k: torch.empty(sh[k], dtype=torch.float64, device=dev) for k in names}
+            for k in names:
+                M.fill_synthetic(full[k], k, 100, 1)
+            arg = full
+        else:
+            arg = {k: sh[k][:-1] for k in names}
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        mine = M.scatter_inputs(arg, ns, src=0, device=dev)
+        torch.cuda.synchronize(); dist.barrier()
+        t_sc = time.perf_counter() - t0
+        M.advect_scalar2D(mine["f"], mine["u"], mine["w"], mine["rho"], mine["rhow"], mine["flux"], mine["adz"])
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        M.gather_outputs({"f": mine["f"], "flux": mine["flux"]}, full if rank == 0 else None, ns, dst=0)
+        torch.cuda.synchronize(); dist.barrier()
+        t_ga = time.perf_counter() - t0
+        if rank == 0:
+            result["scatter_gather"] = {"ncrms": ns, "scatter_s": t_sc, "gather_s": t_ga}
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(nx, nz)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
