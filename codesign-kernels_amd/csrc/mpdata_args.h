@@ -25,7 +25,8 @@ struct MpdataTileInfo {
   int id;
   int W, SPW, NWV;
   int slw;      // CRM instances per workgroup
-  int ncol;     // columns covered (needs nx + 4 <= ncol)
+  int ncol;     // columns covered (needs nx + 4 <= ncol); k-marching kernels only
+  int nz_max;   // largest nz; x-marching kernels only (lanes along k)
   int threads;
   const char* name;
 };

@@ -16,12 +16,12 @@
 #include "mpdata_hip.h"
 
 namespace mpdata_exact {
-int num_tiles();
+int max_tile_id();
 bool tile_info(int id, MpdataTileInfo* info);
 bool launch(int id, const MpdataArgs& a, int ntracers, void* stream);
 }  // namespace mpdata_exact
 namespace mpdata_fast {
-int num_tiles();
+int max_tile_id();
 bool tile_info(int id, MpdataTileInfo* info);
 bool launch(int id, const MpdataArgs& a, int ntracers, void* stream);
 }  // namespace mpdata_fast
@@ -70,26 +70,31 @@ bool get_tile(int var, int id, MpdataTileInfo* t) {
   return var == MPDATA_VARIANT_FAST ? mpdata_fast::tile_info(id, t) : mpdata_exact::tile_info(id, t);
 }
 
-// Smallest column coverage that fits nx (needs nx+4 <= ncol); ties -> lowest id.
-int choose_tile(int var, int nx, MpdataTileInfo* out) {
+// Automatic choice: the x-marching kernel with the fewest lanes per instance
+// that holds nz (lanes along k, any nx); if nz is too large for one wave, the
+// k-marching kernel with the smallest column coverage that fits nx.
+int choose_tile(int var, int nx, int nz, MpdataTileInfo* out) {
   const int forced = tile_override();
   MpdataTileInfo t;
   if (forced >= 0) {
     if (!get_tile(var, forced, &t)) return set_err(MPDATA_EINVAL, "unknown tile id %d", forced);
-    if (t.ncol < nx + 4)
-      return set_err(MPDATA_EUNSUPPORTED, "tile %s covers %d columns, nx=%d needs %d", t.name,
-                     t.ncol, nx, nx + 4);
+    if (t.ncol < nx + 4 || t.nz_max < nz)
+      return set_err(MPDATA_EUNSUPPORTED, "tile %s covers %d columns / nz<=%d; nx=%d nz=%d", t.name,
+                     t.ncol, t.nz_max, nx, nz);
     *out = t;
     return 0;
   }
-  int best = -1, best_ncol = 1 << 30;
-  const int n = var == MPDATA_VARIANT_FAST ? mpdata_fast::num_tiles() : mpdata_exact::num_tiles();
+  int best = -1, best_cost = 1 << 30;
+  const int n = (var == MPDATA_VARIANT_FAST ? mpdata_fast::max_tile_id() : mpdata_exact::max_tile_id()) + 1;
   for (int id = 0; id < n; ++id) {
     if (!get_tile(var, id, &t)) continue;
-    if (t.ncol >= nx + 4 && t.ncol < best_ncol) { best = id; best_ncol = t.ncol; }
+    if (t.ncol < nx + 4 || t.nz_max < nz) continue;
+    // x-marching tiles (finite nz_max) first, by lanes per instance; then k-marching by columns
+    const int cost = t.nz_max < (1 << 30) ? t.nz_max : 100000 + t.ncol;
+    if (cost < best_cost) { best = id; best_cost = cost; }
   }
   if (best < 0)
-    return set_err(MPDATA_EUNSUPPORTED, "nx=%d exceeds the widest kernel tiling", nx);
+    return set_err(MPDATA_EUNSUPPORTED, "no kernel tiling covers nx=%d nz=%d (need nz<=64 or nx<=140)", nx, nz);
   get_tile(var, best, out);
   return 0;
 }
@@ -179,7 +184,7 @@ int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers, d
     return set_err(MPDATA_EINVAL, "null array pointer");
   const int var = variant();
   MpdataTileInfo t;
-  rc = choose_tile(var, nx, &t);
+  rc = choose_tile(var, nx, nz, &t);
   if (rc) return rc;
   MpdataArgs a;
   a.f = f; a.u = u; a.w = w; a.rho = rho; a.rhow = rhow; a.adz = adz; a.flux = flux;
@@ -199,7 +204,7 @@ int mpdata_plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
   MpdataTileInfo t;
-  rc = choose_tile(variant(), nx, &t);
+  rc = choose_tile(variant(), nx, nz, &t);
   if (rc) return rc;
   mpdata_plan* p = (mpdata_plan*)calloc(1, sizeof(mpdata_plan));
   if (!p) return set_err(MPDATA_EINVAL, "out of host memory");

@@ -1,0 +1,293 @@
+// mpdata_kernel_v2_body.h -- "x-marching" fused MPDATA kernel for gfx950.
+//
+// Same arithmetic as mpdata_kernel_body.h (the k-marching kernel), i.e. one call
+// of the reference routine
+//   mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:477-642,
+// but with the roles of the two stencil axes exchanged so that the rolling
+// window fits in ~100 VGPRs (4 waves per SIMD) instead of spilling:
+//
+//   * a LANE owns one (CRM instance sl, vertical level k) pair; a wave holds
+//     64/LPS instances x LPS lanes (LPS >= nz, a power of two); the vertical
+//     neighbours kb = max(1,k-1), kc = min(nzm,k+1) (reference :515-516) are
+//     other lanes of the same wave, fetched with ds_bpermute (LDS crossbar, no
+//     memory, no barrier) through per-lane source indices that realise the
+//     clamps; lane k = nz is a "ghost" level holding w = 0, which makes
+//     www(:,:,:,nz) = 0 (:511) fall out of the arithmetic;
+//   * the kernel marches over the x columns q = -2 .. nx+5; the horizontal
+//     dependencies (radius 3) become a 3-column
+//     software pipeline in registers:
+//         step q:  upwind fluxes of column q, first-pass f1 of column q-1,
+//                  antidiffusive U2 of q-1 and W2 / limiter ratios of q-2,
+//                  limited fluxes of q-2, final field of column q-3;
+//     every condition on q is wave-uniform (scalar branches), so halo columns
+//     cost only the stages they need;
+//   * HBM is read and written in rows that are contiguous along sl.  The 16
+//     instances of a workgroup give 128-byte rows; each step the workgroup
+//     loads the 3*nzm rows (f,u,w) of the next column cooperatively with lanes
+//     along sl, transposes them through LDS (row stride 17 doubles: conflict
+//     free both ways), and writes the finished column back the same way;
+//   * irho, iadz, irhow, dd (:552-553,:565,:569) depend on (sl,k) only and are
+//     computed ONCE per lane, not once per column.
+//
+// f is bit-identical to the reference in the EXACT build.  flux(k) is
+// accumulated per lane as (sum_i upwind) + (sum_i limited), each sum in the
+// reference's i order; the reference adds the limited terms one by one onto
+// the finished upwind sum (:545,:624), so flux differs from it by rounding
+// of the last few ulps (tests bound it at 1e-13 relative).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mpdata_args.h"
+
+namespace MPDATA_NS {
+namespace v2 {
+
+#define MPD2_G 16  // CRM instances per workgroup (128-byte rows)
+
+__device__ __forceinline__ double dmax(double x, double y) { return __builtin_fmax(x, y); }
+__device__ __forceinline__ double dmin(double x, double y) { return __builtin_fmin(x, y); }
+// Statement functions of the reference (:500-503), left-to-right.
+__device__ __forceinline__ double andiff(double x1, double x2, double a, double b) {
+  return (__builtin_fabs(a) - a * a * b) * 0.5 * (x2 - x1);
+}
+__device__ __forceinline__ double across(double x1, double a1, double a2) {
+  return 0.03125 * a1 * a2 * x1;
+}
+__device__ __forceinline__ double pp(double y) { return dmax(0.0, y); }
+__device__ __forceinline__ double pn(double y) { return -dmin(0.0, y); }
+
+// value of `v` held by the lane whose byte index is `addr` (= 4*lane)
+__device__ __forceinline__ double lane_get(int addr, double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_bpermute(addr, lo);
+  hi = __builtin_amdgcn_ds_bpermute(addr, hi);
+  return __hiloint2double(hi, lo);
+}
+
+template <int LPS>
+struct TileV2 {
+  static constexpr int SLP = 64 / LPS;         // instances per wave
+  static constexpr int NWV = MPD2_G / SLP;     // waves per workgroup
+  static constexpr int THREADS = 64 * NWV;     // = 16 * LPS
+  static constexpr int RS = MPD2_G + 1;        // LDS row stride in doubles
+  static constexpr int NZM_MAX = LPS - 1;
+  static constexpr int IN_SLOT = 3 * NZM_MAX * RS;   // f,u,w rows of one column
+  static constexpr int OUT_SLOT = NZM_MAX * RS;
+  static constexpr int LDS_DOUBLES = 2 * IN_SLOT + 2 * OUT_SLOT;
+};
+
+template <int LPS>
+__global__ void __launch_bounds__(16 * LPS)
+mpdata_advect_xmarch_kernel(const MpdataArgs a) {
+  using T = TileV2<LPS>;
+  constexpr int G = MPD2_G, RS = T::RS, SLP = T::SLP;
+  __shared__ double lds[T::LDS_DOUBLES];
+  double* const in_slot0 = lds;
+  double* const out_slot0 = lds + 2 * T::IN_SLOT;
+
+  const int nx = a.nx, nz = a.nz, nzm = nz - 1;
+  const long long ncrms = a.ncrms;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tr = blockIdx.y;
+  const long long sl_base = (long long)blockIdx.x * G;
+
+  double* const f = a.f + (long long)tr * a.f_tstride;
+  double* const flux = a.flux + (long long)tr * a.flux_tstride;
+
+  // ---- compute-side mapping: lane -> (instance, level) ----------------------
+  const int kk = lane % LPS;               // k - 1
+  const int k = kk + 1;
+  const int sl_l = wave * SLP + lane / LPS;  // instance inside the workgroup
+  const bool lvl_ok = k <= nzm;            // real level (else ghost / dead lane)
+  const int kl = lvl_ok ? k : nzm;         // level whose data the lane loads
+  long long sl_c = sl_base + sl_l;
+  const bool slc_ok = sl_c < ncrms;
+  if (!slc_ok) sl_c = ncrms - 1;
+  // lane indices (bytes) of the vertical neighbours, clamps included
+  const int a_dn = ((k == 1 || !lvl_ok) ? lane : lane - 1) * 4;    // kb, clamped at 1
+  const int a_upc = ((k >= nzm) ? lane : lane + 1) * 4;            // kc, clamped at nzm
+  const int a_upg = ((k > nzm || kk == LPS - 1) ? lane : lane + 1) * 4;  // k+1, level nz = ghost (0)
+
+  // per-lane constants (:552, :553, :565, :569)
+  const double eps = (double)1.e-10f;  // :509, fp32 literal
+  const long long kidx = sl_c + ncrms * (long long)(kl - 1);
+  const double RHO = a.rho[kidx];
+  const double adz_l = a.adz[kidx];
+  const double rhow_l = a.rhow[kidx];
+  const double IRHO = 1.0 / RHO;
+  const double IADZ = 1.0 / adz_l;
+  const double IRHOW = 1.0 / (rhow_l * adz_l);
+  const double DD = ((k == 1 || k == nzm) ? 2.0 : 1.0) * IADZ;  // 2./(kc-kb)/adz, exact
+  const bool k_is_1 = k == 1;
+
+  // ---- transfer-side mapping: thread -> (row = level, instance) -------------
+  const int t_row = tid / G;  // level index k-1 of the row this thread moves
+  const int t_sl = tid % G;
+  const bool t_act = t_row < nzm;
+  long long sl_t = sl_base + t_sl;
+  const bool slt_ok = sl_t < ncrms;
+  if (!slt_ok) sl_t = ncrms - 1;
+  const int t_rowc = t_act ? t_row : 0;
+  // element offsets of (column index 0, this level, this instance)
+  const long long tf = sl_t + ncrms * (long long)(nx + 6) * t_rowc;
+  const long long tu = sl_t + ncrms * (long long)(nx + 5) * t_rowc;
+  const long long tw = sl_t + ncrms * (long long)(nx + 4) * t_rowc;
+  const int t_lds = t_rowc * RS + t_sl;          // position inside one array block of a slot
+  const int c_lds = (kl - 1) * RS + sl_l;        // compute-side read position
+
+  // column loader: columns are clamped into each array's range (the clamped
+  // copies are never used by a valid result)
+  double rf = 0, ru = 0, rw = 0;
+  auto load_col = [&](int q) {
+    if (t_act) {
+      const int cf = min(max(q, -2), nx + 3) + 2;
+      const int cu = min(max(q, -1), nx + 3) + 1;
+      const int cw = min(max(q, -1), nx + 2) + 1;
+      rf = f[tf + ncrms * (long long)cf];
+      ru = a.u[tu + ncrms * (long long)cu];
+      rw = a.w[tw + ncrms * (long long)cw];
+    }
+  };
+  auto stage_col = [&](int q) {  // registers -> LDS slot of column q
+    if (t_act) {
+      double* s = in_slot0 + (q & 1) * T::IN_SLOT;
+      s[t_lds] = rf;
+      s[T::NZM_MAX * RS + t_lds] = ru;
+      s[2 * T::NZM_MAX * RS + t_lds] = rw;
+    }
+  };
+
+  // ---- rolling state (names: _1 = column q-1, _2 = q-2, _3 = q-3) ----------
+  double F0p = 0, PMX = 0, PMN = 0, U1p = 0, DW1p = 0;
+  double F1_2 = 0, F1_3 = 0, F1D_2 = 0, F1D_3 = 0, F1U_2 = 0;
+  double MX0_2 = 0, MN0_2 = 0;
+  double Uraw_1 = 0, UD_1 = 0, SU_2 = 0;
+  double PW_1 = 0, SW_1 = 0, W_1 = 0, W_2 = 0;
+  double U2_2 = 0, MXN_3 = 0, MNN_3 = 0, U3_3 = 0, DW3_3 = 0;
+  double S1 = 0, S3 = 0;
+
+  const int q_first = -2, q_last = nx + 5;
+  load_col(q_first);
+  stage_col(q_first);
+
+  for (int q = q_first; q <= q_last; ++q) {
+    __syncthreads();  // column q staged; finished column q-4 in the out slot
+    if (q + 1 <= nx + 3) load_col(q + 1);  // next column into flight
+
+    // ---- write back the column finished in the previous step (n = q-4) ------
+    {
+      const int n = q - 4;
+      if (n >= -1 && n <= nx + 2 && t_act && slt_ok) {
+        const double* o = out_slot0 + ((q - 1) & 1) * T::OUT_SLOT;
+        f[tf + ncrms * (long long)(n + 2)] = o[t_lds];
+      }
+    }
+
+    // ---- this column, transposed: lanes along k -------------------------------
+    const double* s = in_slot0 + (q & 1) * T::IN_SLOT;
+    const double f0q = s[c_lds];
+    const double uq = s[T::NZM_MAX * RS + c_lds];
+    const double wq = lvl_ok ? s[2 * T::NZM_MAX * RS + c_lds] : 0.0;  // ghost level: w = 0
+
+    const double f0d = lane_get(a_dn, f0q);
+    const double f0u = lane_get(a_upc, f0q);
+
+    // ================= stage A =================================================
+    double U1q = 0, DW1q = 0, f1_1 = 0, F1D_1 = 0, F1U_1 = 0, MX0_1 = 0, MN0_1 = 0;
+    if (q >= -1 && q <= nx + 3) {
+      U1q = dmax(0.0, uq) * F0p + dmin(0.0, uq) * f0q;  // :532
+      if (q <= nx + 2) {
+        const double W1q = dmax(0.0, wq) * f0d + dmin(0.0, wq) * f0q;  // :537
+        DW1q = lane_get(a_upg, W1q) - W1q;
+        if (q >= 1 && q <= nx) S1 = S1 + W1q;  // :545
+      }
+      if (q >= 0) {
+        f1_1 = F0p - ((U1q - U1p) + DW1p * IADZ) * IRHO;  // :557, column q-1
+        F1D_1 = lane_get(a_dn, f1_1);
+        F1U_1 = lane_get(a_upc, f1_1);
+        MX0_1 = dmax(PMX, f0q);  // :521-522 complete for column q-1
+        MN0_1 = dmin(PMN, f0q);
+      }
+    }
+    // :521-522 for column q without its f(ic) term
+    const double PMXn = dmax(dmax(dmax(F0p, f0d), f0u), f0q);
+    const double PMNn = dmin(dmin(dmin(F0p, f0d), f0u), f0q);
+
+    // u / w sums for the antidiffusive cross terms (:573, :582), reference order
+    const double ud = lane_get(a_dn, uq);
+    const double SUq = UD_1 + Uraw_1 + uq + ud;   // u(i,kb)+u(i,k)+u(ic,k)+u(ic,kb), i = q-1
+    const double wu = lane_get(a_upc, wq);
+    const double PWq = wq + wu;
+    const double SWq = PW_1 + wq + wu;            // w(ib,k)+w(ib,kc)+w(i,k)+w(i,kc), i = q
+
+    // ================= stage B/C ===============================================
+    double U2_1 = 0, MXN_2 = 0, MNN_2 = 0, W2_2 = 0;
+    if (q >= 1 && q <= nx + 3) {
+      {  // :571-573, column q-1
+        const double ad = andiff(F1_2, f1_1, Uraw_1, IRHO);
+        const double x = DD * (F1U_2 + F1U_1 - F1D_2 - F1D_1);
+        U2_1 = ad - across(x, Uraw_1, SW_1) * IRHO;
+      }
+      if (q >= 2) {  // column q-2
+        {  // :580-582, :586
+          const double ad = andiff(F1D_2, F1_2, W_2, IRHOW);
+          const double x = F1D_1 + f1_1 - F1D_3 - F1_3;
+          const double v = ad - across(x, W_2, SU_2) * IRHO;
+          W2_2 = k_is_1 ? 0.0 : v;
+        }
+        const double W2u = lane_get(a_upc, W2_2);
+        // :596-597
+        const double mx1 = dmax(dmax(dmax(dmax(dmax(F1_3, f1_1), F1D_2), F1U_2), F1_2), MX0_2);
+        const double mn1 = dmin(dmin(dmin(dmin(dmin(F1_3, f1_1), F1D_2), F1U_2), F1_2), MN0_2);
+        // :606-609
+        MXN_2 = RHO * (mx1 - F1_2) / (pn(U2_1) + pp(U2_2) + IADZ * (pn(W2u) + pp(W2_2)) + eps);
+        MNN_2 = RHO * (F1_2 - mn1) / (pp(U2_1) + pn(U2_2) + IADZ * (pp(W2u) + pn(W2_2)) + eps);
+      }
+    }
+
+    // ================= stage D =================================================
+    double U3_2 = 0, DW3_2 = 0;
+    if (q >= 3 && q <= nx + 3) {
+      U3_2 = pp(U2_2) * dmin(dmin(1.0, MXN_2), MNN_3) - pn(U2_2) * dmin(dmin(1.0, MXN_3), MNN_2);  // :618
+      if (q <= nx + 2) {
+        const double mxd = lane_get(a_dn, MXN_2);
+        const double mnd = lane_get(a_dn, MNN_2);
+        const double W3 = pp(W2_2) * dmin(dmin(1.0, MXN_2), mnd) - pn(W2_2) * dmin(dmin(1.0, mxd), MNN_2);  // :623
+        S3 = S3 + W3;  // :624
+        DW3_2 = lane_get(a_upg, W3) - W3;
+      }
+    }
+    {
+      const int n = q - 3;  // column finished in this step
+      if (n >= -1 && n <= nx + 2) {
+        double v = F1_3;  // halo columns keep the first-pass value (:557)
+        if (n >= 1 && n <= nx)
+          v = dmax(0.0, F1_3 - ((U3_2 - U3_3) + DW3_3 * IADZ) * IRHO);  // :634
+        if (lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = v;
+      }
+    }
+
+    // ================= rotate ==================================================
+    F0p = f0q; PMX = PMXn; PMN = PMNn; U1p = U1q; DW1p = DW1q;
+    F1_3 = F1_2; F1_2 = f1_1; F1D_3 = F1D_2; F1D_2 = F1D_1; F1U_2 = F1U_1;
+    MX0_2 = MX0_1; MN0_2 = MN0_1;
+    Uraw_1 = uq; UD_1 = ud; SU_2 = SUq;
+    PW_1 = PWq; SW_1 = SWq; W_2 = W_1; W_1 = wq;
+    U2_2 = U2_1; MXN_3 = MXN_2; MNN_3 = MNN_2; U3_3 = U3_2; DW3_3 = DW3_2;
+
+    if (q + 1 <= nx + 3) stage_col(q + 1);
+  }
+
+  // ---- last finished column (n = nx+2) and flux ------------------------------
+  __syncthreads();
+  if (t_act && slt_ok) {
+    const double* o = out_slot0 + (q_last & 1) * T::OUT_SLOT;
+    f[tf + ncrms * (long long)(nx + 2 + 2)] = o[t_lds];
+  }
+  if (lvl_ok && slc_ok) flux[sl_c + ncrms * (long long)(k - 1)] = S1 + S3;  // :541-547, :624
+}
+
+}  // namespace v2
+}  // namespace MPDATA_NS

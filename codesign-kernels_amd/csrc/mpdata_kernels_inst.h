@@ -2,6 +2,7 @@
 // Included by mpdata_kernels_exact.hip / mpdata_kernels_fast.hip after
 // defining MPDATA_NS; exports <MPDATA_NS>::launch(tile, ...).
 #include "mpdata_kernel_body.h"
+#include "mpdata_kernel_v2_body.h"
 
 namespace MPDATA_NS {
 
@@ -19,25 +20,49 @@ static void launch_tile(const MpdataArgs& a, int ntracers, void* stream) {
   X(1, 9, 1, 4)         \
   X(2, 9, 2, 2)         \
   X(3, 9, 4, 2)         \
-  X(4, 9, 4, 4)
+  X(4, 9, 4, 4)         \
+  X(5, 3, 4, 3)         \
+  X(6, 1, 4, 9)         \
+  X(7, 2, 2, 9)         \
+  X(8, 6, 2, 3)         \
+  X(9, 3, 2, 6)         \
+  X(10, 3, 1, 12)
 
-int num_tiles() {
-  int n = 0;
-#define X(id, W, SPW, NWV) ++n;
-  MPDATA_TILES(X)
-#undef X
-  return n;
+// x-marching kernels (mpdata_kernel_v2_body.h): id, LPS (lanes per instance >= nz)
+#define MPDATA_TILES_V2(X) \
+  X(20, 8)                 \
+  X(21, 16)                \
+  X(22, 32)                \
+  X(23, 64)
+
+template <int LPS>
+static void launch_tile_v2(const MpdataArgs& a, int ntracers, void* stream) {
+  using T = v2::TileV2<LPS>;
+  const unsigned gx = (unsigned)((a.ncrms + MPD2_G - 1) / MPD2_G);
+  dim3 grid(gx, (unsigned)ntracers, 1), block(T::THREADS, 1, 1);
+  hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<LPS>), grid, block, 0, (hipStream_t)stream, a);
 }
+
+int max_tile_id() { return 23; }
 
 bool tile_info(int id, MpdataTileInfo* info) {
 #define X(ID, W_, SPW_, NWV_)                                                     \
   if (id == ID) {                                                                 \
     using T = Tile<W_, SPW_, NWV_>;                                               \
-    *info = MpdataTileInfo{ID, W_, SPW_, NWV_, T::SLW, T::NCOL, T::THREADS,       \
-                           "W" #W_ "_SPW" #SPW_ "_NWV" #NWV_};                    \
+    *info = MpdataTileInfo{ID, W_, SPW_, NWV_, T::SLW, T::NCOL, 1 << 30, T::THREADS, \
+                           "kmarch_W" #W_ "_SPW" #SPW_ "_NWV" #NWV_};             \
     return true;                                                                  \
   }
   MPDATA_TILES(X)
+#undef X
+#define X(ID, LPS_)                                                                      \
+  if (id == ID) {                                                                        \
+    using T = v2::TileV2<LPS_>;                                                          \
+    *info = MpdataTileInfo{ID, 0, 0, T::NWV, MPD2_G, 1 << 30, LPS_, T::THREADS,          \
+                           "xmarch_LPS" #LPS_};                                          \
+    return true;                                                                         \
+  }
+  MPDATA_TILES_V2(X)
 #undef X
   return false;
 }
@@ -49,6 +74,13 @@ bool launch(int id, const MpdataArgs& a, int ntracers, void* stream) {
     return true;                                       \
   }
   MPDATA_TILES(X)
+#undef X
+#define X(ID, LPS_)                               \
+  if (id == ID) {                                 \
+    launch_tile_v2<LPS_>(a, ntracers, stream);    \
+    return true;                                  \
+  }
+  MPDATA_TILES_V2(X)
 #undef X
   return false;
 }
