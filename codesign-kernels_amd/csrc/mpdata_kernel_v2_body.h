@@ -19,8 +19,10 @@
 //         step q:  upwind fluxes of column q, first-pass f1 of column q-1,
 //                  antidiffusive U2 of q-1 and W2 / limiter ratios of q-2,
 //                  limited fluxes of q-2, final field of column q-3;
-//     every condition on q is wave-uniform (scalar branches), so halo columns
-//     cost only the stages they need;
+//     every condition on q is wave-uniform; the steady-state columns
+//     (4 <= q <= nx) run a condition-free body, and the rolling window is a set
+//     of 3-slot rings indexed by (column mod 3) with the loop unrolled by 3, so
+//     no register-to-register rotation is executed;
 //   * HBM is read and written in rows that are contiguous along sl.  The 16
 //     instances of a workgroup give 128-byte rows; each step the workgroup
 //     loads the 3*nzm rows (f,u,w) of the next column cooperatively with lanes
@@ -34,9 +36,16 @@
 // reference's i order; the reference adds the limited terms one by one onto
 // the finished upwind sum (:545,:624), so flux differs from it by rounding
 // of the last few ulps (tests bound it at 1e-13 relative).
+//
+// Built with -fno-honor-nans: fmax/fmin then need no operand canonicalisation
+// (v_max_f64 x,x).  No value-changing transformation is enabled by it; inputs
+// containing NaN are outside the contract (the reference's own max/min
+// intrinsics are processor-dependent on NaN as well).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "mpdata_args.h"
 
@@ -44,6 +53,9 @@ namespace MPDATA_NS {
 namespace v2 {
 
 #define MPD2_G 16  // CRM instances per workgroup (128-byte rows)
+#ifndef MPD2_USE_FULL
+#define MPD2_USE_FULL 0  // 1: condition-free steady-state body (higher register pressure)
+#endif
 
 __device__ __forceinline__ double dmax(double x, double y) { return __builtin_fmax(x, y); }
 __device__ __forceinline__ double dmin(double x, double y) { return __builtin_fmin(x, y); }
@@ -56,6 +68,26 @@ __device__ __forceinline__ double across(double x1, double a1, double a2) {
 }
 __device__ __forceinline__ double pp(double y) { return dmax(0.0, y); }
 __device__ __forceinline__ double pn(double y) { return -dmin(0.0, y); }
+
+// n / d for the limiter ratios (:606-609).  d >= eps > 0 and everything is
+// finite there.  EXACT: the IEEE-correct quotient.  FAST (MPDATA_FAST_DIV):
+// reciprocal + two Newton steps + one residual correction, without the
+// scale/fixup handling of subnormal and huge operands the limiter never sees
+// (result within 1 ulp of the correctly rounded quotient).
+__device__ __forceinline__ double ratio(double n, double d) {
+#ifdef MPDATA_FAST_DIV
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = n * r;
+  const double rem = __builtin_fma(-d, q, n);
+  return __builtin_fma(rem, r, q);
+#else
+  return n / d;
+#endif
+}
 
 // value of `v` held by the lane whose byte index is `addr` (= 4*lane)
 __device__ __forceinline__ double lane_get(int addr, double v) {
@@ -77,8 +109,17 @@ struct TileV2 {
   static constexpr int LDS_DOUBLES = 2 * IN_SLOT + 2 * OUT_SLOT;
 };
 
+// Rolling window: rings of 3 slots indexed by (column mod 3).
+struct Window {
+  double F0[3], PMX[3], PMN[3], U1[3], DW1[3];      // written for column q
+  double F1[3], F1D[3], F1U[3], MX0[3], MN0[3];     // written for column q-1
+  double UR[3], UD[3], PW[3], SW[3], WR[3];         // u, u(kb), w+w(kc), w-sum, w of column q
+  double SU[3], U2[3];                              // written for column q-1
+  double MXN[3], MNN[3], U3[3], DW3[3];             // written for column q-2
+};
+
 template <int LPS>
-__global__ void __launch_bounds__(16 * LPS)
+__global__ void __launch_bounds__(16 * LPS, 4)
 mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   using T = TileV2<LPS>;
   constexpr int G = MPD2_G, RS = T::RS, SLP = T::SLP;
@@ -136,53 +177,45 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   const long long tw = sl_t + ncrms * (long long)(nx + 4) * t_rowc;
   const int t_lds = t_rowc * RS + t_sl;          // position inside one array block of a slot
   const int c_lds = (kl - 1) * RS + sl_l;        // compute-side read position
+  const bool t_st = t_act && slt_ok;
 
-  // column loader: columns are clamped into each array's range (the clamped
-  // copies are never used by a valid result)
-  double rf = 0, ru = 0, rw = 0;
-  auto load_col = [&](int q) {
-    if (t_act) {
-      const int cf = min(max(q, -2), nx + 3) + 2;
-      const int cu = min(max(q, -1), nx + 3) + 1;
-      const int cw = min(max(q, -1), nx + 2) + 1;
-      rf = f[tf + ncrms * (long long)cf];
-      ru = a.u[tu + ncrms * (long long)cu];
-      rw = a.w[tw + ncrms * (long long)cw];
-    }
-  };
-  auto stage_col = [&](int q) {  // registers -> LDS slot of column q
-    if (t_act) {
-      double* s = in_slot0 + (q & 1) * T::IN_SLOT;
-      s[t_lds] = rf;
-      s[T::NZM_MAX * RS + t_lds] = ru;
-      s[2 * T::NZM_MAX * RS + t_lds] = rw;
-    }
-  };
+  double rf = 0, ru = 0, rw = 0;  // the column in flight
 
-  // ---- rolling state (names: _1 = column q-1, _2 = q-2, _3 = q-3) ----------
-  double F0p = 0, PMX = 0, PMN = 0, U1p = 0, DW1p = 0;
-  double F1_2 = 0, F1_3 = 0, F1D_2 = 0, F1D_3 = 0, F1U_2 = 0;
-  double MX0_2 = 0, MN0_2 = 0;
-  double Uraw_1 = 0, UD_1 = 0, SU_2 = 0;
-  double PW_1 = 0, SW_1 = 0, W_1 = 0, W_2 = 0;
-  double U2_2 = 0, MXN_3 = 0, MNN_3 = 0, U3_3 = 0, DW3_3 = 0;
+  Window S;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    S.F0[j] = S.PMX[j] = S.PMN[j] = S.U1[j] = S.DW1[j] = 0.0;
+    S.F1[j] = S.F1D[j] = S.F1U[j] = S.MX0[j] = S.MN0[j] = 0.0;
+    S.UR[j] = S.UD[j] = S.PW[j] = S.SW[j] = S.WR[j] = S.SU[j] = S.U2[j] = 0.0;
+    S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = 0.0;
+  }
   double S1 = 0, S3 = 0;
 
-  const int q_first = -2, q_last = nx + 5;
-  load_col(q_first);
-  stage_col(q_first);
+  // One step of the march.  PH = (q+2) mod 3 selects the ring slots at compile
+  // time; FULL = steady state (4 <= q <= nx): every stage is active.
+  auto step = [&](auto ph_tag, auto full_tag, const int q) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_tag)::value;
+    constexpr bool FULL = decltype(full_tag)::value;
+    constexpr int C0 = PH, C1 = (PH + 2) % 3, C2 = (PH + 1) % 3, C3 = PH;  // slots of q, q-1, q-2, q-3
 
-  for (int q = q_first; q <= q_last; ++q) {
     __syncthreads();  // column q staged; finished column q-4 in the out slot
-    if (q + 1 <= nx + 3) load_col(q + 1);  // next column into flight
 
-    // ---- write back the column finished in the previous step (n = q-4) ------
-    {
-      const int n = q - 4;
-      if (n >= -1 && n <= nx + 2 && t_act && slt_ok) {
-        const double* o = out_slot0 + ((q - 1) & 1) * T::OUT_SLOT;
-        f[tf + ncrms * (long long)(n + 2)] = o[t_lds];
+    // ---- next column into flight (columns clamped into each array's range;
+    //      a clamped copy is never used by a valid result)
+    if (FULL || q + 1 <= nx + 3) {
+      if (t_act) {
+        const int q1 = q + 1;
+        const int cf = FULL ? q1 + 2 : min(max(q1, -2), nx + 3) + 2;
+        const int cu = FULL ? q1 + 1 : min(max(q1, -1), nx + 3) + 1;
+        const int cw = FULL ? q1 + 1 : min(max(q1, -1), nx + 2) + 1;
+        rf = f[tf + ncrms * (long long)cf];
+        ru = a.u[tu + ncrms * (long long)cu];
+        rw = a.w[tw + ncrms * (long long)cw];
       }
+    }
+    // ---- write back the column finished in the previous step (n = q-4) ------
+    if (FULL || (q - 4 >= -1 && q - 4 <= nx + 2)) {
+      if (t_st) f[tf + ncrms * (long long)(q - 4 + 2)] = out_slot0[((q - 1) & 1) * T::OUT_SLOT + t_lds];
     }
 
     // ---- this column, transposed: lanes along k -------------------------------
@@ -193,99 +226,150 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 
     const double f0d = lane_get(a_dn, f0q);
     const double f0u = lane_get(a_upc, f0q);
+    const double F0p = S.F0[C1];
 
     // ================= stage A =================================================
-    double U1q = 0, DW1q = 0, f1_1 = 0, F1D_1 = 0, F1U_1 = 0, MX0_1 = 0, MN0_1 = 0;
-    if (q >= -1 && q <= nx + 3) {
+    // (every ring slot is written unconditionally so that the slot of column
+    //  q-3 is dead afterwards: inactive stages store zeros)
+    double U1q = 0.0, DW1q = 0.0, f1_1 = 0.0, F1D_1 = 0.0, F1U_1 = 0.0, MX0_1 = 0.0, MN0_1 = 0.0;
+    if (FULL || (q >= -1 && q <= nx + 3)) {
       U1q = dmax(0.0, uq) * F0p + dmin(0.0, uq) * f0q;  // :532
-      if (q <= nx + 2) {
+      if (FULL || q <= nx + 2) {
         const double W1q = dmax(0.0, wq) * f0d + dmin(0.0, wq) * f0q;  // :537
         DW1q = lane_get(a_upg, W1q) - W1q;
-        if (q >= 1 && q <= nx) S1 = S1 + W1q;  // :545
+        if (FULL || (q >= 1 && q <= nx)) S1 = S1 + W1q;  // :545
       }
-      if (q >= 0) {
-        f1_1 = F0p - ((U1q - U1p) + DW1p * IADZ) * IRHO;  // :557, column q-1
+      if (FULL || q >= 0) {
+        f1_1 = F0p - ((U1q - S.U1[C1]) + S.DW1[C1] * IADZ) * IRHO;  // :557, column q-1
         F1D_1 = lane_get(a_dn, f1_1);
         F1U_1 = lane_get(a_upc, f1_1);
-        MX0_1 = dmax(PMX, f0q);  // :521-522 complete for column q-1
-        MN0_1 = dmin(PMN, f0q);
+        MX0_1 = dmax(S.PMX[C1], f0q);  // :521-522 complete for column q-1
+        MN0_1 = dmin(S.PMN[C1], f0q);
       }
     }
+    S.U1[C0] = U1q;
+    S.DW1[C0] = DW1q;
+    S.F1[C1] = f1_1;
+    S.F1D[C1] = F1D_1;
+    S.F1U[C1] = F1U_1;
+    S.MX0[C1] = MX0_1;
+    S.MN0[C1] = MN0_1;
     // :521-522 for column q without its f(ic) term
-    const double PMXn = dmax(dmax(dmax(F0p, f0d), f0u), f0q);
-    const double PMNn = dmin(dmin(dmin(F0p, f0d), f0u), f0q);
+    S.PMX[C0] = dmax(dmax(dmax(F0p, f0d), f0u), f0q);
+    S.PMN[C0] = dmin(dmin(dmin(F0p, f0d), f0u), f0q);
+    S.F0[C0] = f0q;
 
     // u / w sums for the antidiffusive cross terms (:573, :582), reference order
     const double ud = lane_get(a_dn, uq);
-    const double SUq = UD_1 + Uraw_1 + uq + ud;   // u(i,kb)+u(i,k)+u(ic,k)+u(ic,kb), i = q-1
+    S.SU[C1] = S.UD[C1] + S.UR[C1] + uq + ud;  // u(i,kb)+u(i,k)+u(ic,k)+u(ic,kb), i = q-1
+    S.UR[C0] = uq;
+    S.UD[C0] = ud;
     const double wu = lane_get(a_upc, wq);
-    const double PWq = wq + wu;
-    const double SWq = PW_1 + wq + wu;            // w(ib,k)+w(ib,kc)+w(i,k)+w(i,kc), i = q
+    S.SW[C0] = S.PW[C1] + wq + wu;             // w(ib,k)+w(ib,kc)+w(i,k)+w(i,kc), i = q
+    S.PW[C0] = wq + wu;
+    S.WR[C0] = wq;
 
     // ================= stage B/C ===============================================
-    double U2_1 = 0, MXN_2 = 0, MNN_2 = 0, W2_2 = 0;
-    if (q >= 1 && q <= nx + 3) {
+    double U2_1 = 0.0, W2_2 = 0.0, MXN_2 = 0.0, MNN_2 = 0.0;
+    if (FULL || (q >= 1 && q <= nx + 3)) {
       {  // :571-573, column q-1
-        const double ad = andiff(F1_2, f1_1, Uraw_1, IRHO);
-        const double x = DD * (F1U_2 + F1U_1 - F1D_2 - F1D_1);
-        U2_1 = ad - across(x, Uraw_1, SW_1) * IRHO;
+        const double ad = andiff(S.F1[C2], f1_1, S.UR[C1], IRHO);
+        const double x = DD * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1);
+        U2_1 = ad - across(x, S.UR[C1], S.SW[C1]) * IRHO;
       }
-      if (q >= 2) {  // column q-2
+      if (FULL || q >= 2) {  // column q-2
         {  // :580-582, :586
-          const double ad = andiff(F1D_2, F1_2, W_2, IRHOW);
-          const double x = F1D_1 + f1_1 - F1D_3 - F1_3;
-          const double v = ad - across(x, W_2, SU_2) * IRHO;
+          const double ad = andiff(S.F1D[C2], S.F1[C2], S.WR[C2], IRHOW);
+          const double x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
+          const double v = ad - across(x, S.WR[C2], S.SU[C2]) * IRHO;
           W2_2 = k_is_1 ? 0.0 : v;
         }
         const double W2u = lane_get(a_upc, W2_2);
         // :596-597
-        const double mx1 = dmax(dmax(dmax(dmax(dmax(F1_3, f1_1), F1D_2), F1U_2), F1_2), MX0_2);
-        const double mn1 = dmin(dmin(dmin(dmin(dmin(F1_3, f1_1), F1D_2), F1U_2), F1_2), MN0_2);
+        const double mx1 = dmax(dmax(dmax(dmax(dmax(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MX0[C2]);
+        const double mn1 = dmin(dmin(dmin(dmin(dmin(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MN0[C2]);
         // :606-609
-        MXN_2 = RHO * (mx1 - F1_2) / (pn(U2_1) + pp(U2_2) + IADZ * (pn(W2u) + pp(W2_2)) + eps);
-        MNN_2 = RHO * (F1_2 - mn1) / (pp(U2_1) + pn(U2_2) + IADZ * (pp(W2u) + pn(W2_2)) + eps);
+        MXN_2 = ratio(RHO * (mx1 - S.F1[C2]),
+                      pn(U2_1) + pp(S.U2[C2]) + IADZ * (pn(W2u) + pp(W2_2)) + eps);
+        MNN_2 = ratio(RHO * (S.F1[C2] - mn1),
+                      pp(U2_1) + pn(S.U2[C2]) + IADZ * (pp(W2u) + pn(W2_2)) + eps);
       }
     }
+    S.U2[C1] = U2_1;
+    S.MXN[C2] = MXN_2;
+    S.MNN[C2] = MNN_2;
 
     // ================= stage D =================================================
-    double U3_2 = 0, DW3_2 = 0;
-    if (q >= 3 && q <= nx + 3) {
-      U3_2 = pp(U2_2) * dmin(dmin(1.0, MXN_2), MNN_3) - pn(U2_2) * dmin(dmin(1.0, MXN_3), MNN_2);  // :618
-      if (q <= nx + 2) {
+    double U3_2 = 0.0, DW3_2 = 0.0;
+    if (FULL || (q >= 3 && q <= nx + 3)) {
+      U3_2 = pp(S.U2[C2]) * dmin(dmin(1.0, MXN_2), S.MNN[C3]) -
+             pn(S.U2[C2]) * dmin(dmin(1.0, S.MXN[C3]), MNN_2);  // :618
+      if (FULL || q <= nx + 2) {
         const double mxd = lane_get(a_dn, MXN_2);
         const double mnd = lane_get(a_dn, MNN_2);
-        const double W3 = pp(W2_2) * dmin(dmin(1.0, MXN_2), mnd) - pn(W2_2) * dmin(dmin(1.0, mxd), MNN_2);  // :623
+        const double W3 = pp(W2_2) * dmin(dmin(1.0, MXN_2), mnd) -
+                          pn(W2_2) * dmin(dmin(1.0, mxd), MNN_2);  // :623
         S3 = S3 + W3;  // :624
         DW3_2 = lane_get(a_upg, W3) - W3;
       }
     }
     {
       const int n = q - 3;  // column finished in this step
-      if (n >= -1 && n <= nx + 2) {
-        double v = F1_3;  // halo columns keep the first-pass value (:557)
-        if (n >= 1 && n <= nx)
-          v = dmax(0.0, F1_3 - ((U3_2 - U3_3) + DW3_3 * IADZ) * IRHO);  // :634
+      if (FULL || (n >= -1 && n <= nx + 2)) {
+        double v = S.F1[C3];  // halo columns keep the first-pass value (:557)
+        if (FULL || (n >= 1 && n <= nx))
+          v = dmax(0.0, S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
         if (lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = v;
       }
     }
+    S.U3[C2] = U3_2;
+    S.DW3[C2] = DW3_2;
 
-    // ================= rotate ==================================================
-    F0p = f0q; PMX = PMXn; PMN = PMNn; U1p = U1q; DW1p = DW1q;
-    F1_3 = F1_2; F1_2 = f1_1; F1D_3 = F1D_2; F1D_2 = F1D_1; F1U_2 = F1U_1;
-    MX0_2 = MX0_1; MN0_2 = MN0_1;
-    Uraw_1 = uq; UD_1 = ud; SU_2 = SUq;
-    PW_1 = PWq; SW_1 = SWq; W_2 = W_1; W_1 = wq;
-    U2_2 = U2_1; MXN_3 = MXN_2; MNN_3 = MNN_2; U3_3 = U3_2; DW3_3 = DW3_2;
+    // ---- stage the column that was in flight ----------------------------------
+    if (FULL || q + 1 <= nx + 3) {
+      if (t_act) {
+        double* d = in_slot0 + ((q + 1) & 1) * T::IN_SLOT;
+        d[t_lds] = rf;
+        d[T::NZM_MAX * RS + t_lds] = ru;
+        d[2 * T::NZM_MAX * RS + t_lds] = rw;
+      }
+    }
+  };
 
-    if (q + 1 <= nx + 3) stage_col(q + 1);
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using Full = std::true_type;
+  using Part = std::false_type;
+
+  const int q_first = -2;
+  // first column
+  if (t_act) {
+    rf = f[tf];
+    ru = a.u[tu];
+    rw = a.w[tw];
+    double* d = in_slot0;  // slot (q_first & 1) == 0
+    d[t_lds] = rf;
+    d[T::NZM_MAX * RS + t_lds] = ru;
+    d[2 * T::NZM_MAX * RS + t_lds] = rw;
   }
 
-  // ---- last finished column (n = nx+2) and flux ------------------------------
-  __syncthreads();
-  if (t_act && slt_ok) {
-    const double* o = out_slot0 + (q_last & 1) * T::OUT_SLOT;
-    f[tf + ncrms * (long long)(nx + 2 + 2)] = o[t_lds];
+  // q advances by 3 per trip so that the ring phase is a compile-time constant.
+  // Steps always run in whole triples (no step is skipped, so no ring slot stays
+  // live across the loop edge); the march needs q up to nx+6 (write-back of the
+  // last halo column), any further step of the last triple does nothing.
+  for (int q = q_first; q <= nx + 6; q += 3) {
+    if (MPD2_USE_FULL && q >= 4 && q + 2 <= nx) {
+      step(P0{}, Full{}, q);
+      step(P1{}, Full{}, q + 1);
+      step(P2{}, Full{}, q + 2);
+    } else {
+      step(P0{}, Part{}, q);
+      step(P1{}, Part{}, q + 1);
+      step(P2{}, Part{}, q + 2);
+    }
   }
+
   if (lvl_ok && slc_ok) flux[sl_c + ncrms * (long long)(k - 1)] = S1 + S3;  // :541-547, :624
 }
 
