@@ -18,7 +18,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(HERE, "libmpdata_hip.so")
+# MPDATA_HIP_LIB: load an alternative build of the library (kernel experiments)
+_LIB_PATH = os.environ.get("MPDATA_HIP_LIB") or os.path.join(HERE, "libmpdata_hip.so")
 VARIANT_EXACT, VARIANT_FAST = 0, 1
 
 _lib = None
@@ -80,6 +81,8 @@ def lib():
         L.mpdata_get_variant.restype = ci
         L.mpdata_set_tile.restype = ci
         L.mpdata_set_tile.argtypes = [ci]
+        L.mpdata_set_debug_buffer.restype = ci
+        L.mpdata_set_debug_buffer.argtypes = [vp]
         L.mpdata_device_count.restype = ci
         L.mpdata_algorithmic_bytes.restype = i64
         L.mpdata_algorithmic_bytes.argtypes = [i64, ci, ci, ci]

@@ -17,6 +17,7 @@ struct MpdataArgs {
   int nx, nz;
   long long f_tstride;     // elements between consecutive tracers of f
   long long flux_tstride;  // ... of flux
+  unsigned long long* dbg;  // diagnostic builds only (-DMPD2_STAMPS): in-kernel clock stamps; else null
 };
 
 // One tiling of the kernel template (W columns per thread, SPW strips per

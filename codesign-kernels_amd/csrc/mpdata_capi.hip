@@ -31,6 +31,7 @@ namespace {
 thread_local std::string g_err;
 int g_variant = -1;  // -1: read MPDATA_VARIANT on first use
 int g_tile = -2;     // -2: read MPDATA_TILE on first use; -1: automatic
+unsigned long long* g_dbg = nullptr;  // diagnostic stamp buffer (device), see mpdata_set_debug_buffer
 
 int set_err(int code, const char* fmt, ...) {
   char buf[512];
@@ -73,12 +74,14 @@ bool get_tile(int var, int id, MpdataTileInfo* t) {
 // Automatic choice: the x-marching kernel with the fewest lanes per instance
 // that holds nz (lanes along k, any nx); if nz is too large for one wave, the
 // k-marching kernel with the smallest column coverage that fits nx.
-int choose_tile(int var, int nx, int nz, MpdataTileInfo* out) {
+int choose_tile(int var, int64_t ncrms, int nx, int nz, MpdataTileInfo* out) {
+  // the x-marching kernels address rows with 32-bit byte offsets inside one array
+  const bool small32 = (double)ncrms * (nx + 6) * nz * 8.0 < 4294967296.0;
   const int forced = tile_override();
   MpdataTileInfo t;
   if (forced >= 0) {
     if (!get_tile(var, forced, &t)) return set_err(MPDATA_EINVAL, "unknown tile id %d", forced);
-    if (t.ncol < nx + 4 || t.nz_max < nz)
+    if (t.ncol < nx + 4 || t.nz_max < nz || (t.nz_max < (1 << 30) && !small32))
       return set_err(MPDATA_EUNSUPPORTED, "tile %s covers %d columns / nz<=%d; nx=%d nz=%d", t.name,
                      t.ncol, t.nz_max, nx, nz);
     *out = t;
@@ -89,6 +92,7 @@ int choose_tile(int var, int nx, int nz, MpdataTileInfo* out) {
   for (int id = 0; id < n; ++id) {
     if (!get_tile(var, id, &t)) continue;
     if (t.ncol < nx + 4 || t.nz_max < nz) continue;
+    if (t.nz_max < (1 << 30) && !small32) continue;
     // x-marching tiles (finite nz_max) first, by lanes per instance; then k-marching by columns
     const int cost = t.nz_max < (1 << 30) ? t.nz_max : 100000 + t.ncol;
     if (cost < best_cost) { best = id; best_cost = cost; }
@@ -184,13 +188,14 @@ int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers, d
     return set_err(MPDATA_EINVAL, "null array pointer");
   const int var = variant();
   MpdataTileInfo t;
-  rc = choose_tile(var, nx, nz, &t);
+  rc = choose_tile(var, ncrms, nx, nz, &t);
   if (rc) return rc;
   MpdataArgs a;
   a.f = f; a.u = u; a.w = w; a.rho = rho; a.rhow = rhow; a.adz = adz; a.flux = flux;
   a.ncrms = ncrms; a.nx = nx; a.nz = nz;
   a.f_tstride = (long long)ncrms * (nx + 6) * (nz - 1);
   a.flux_tstride = (long long)ncrms * nz;
+  a.dbg = g_dbg;
   const bool ok = var == MPDATA_VARIANT_FAST ? mpdata_fast::launch(t.id, a, ntracers, stream)
                                              : mpdata_exact::launch(t.id, a, ntracers, stream);
   if (!ok) return set_err(MPDATA_EINVAL, "tile %d not instantiated", t.id);
@@ -204,7 +209,7 @@ int mpdata_plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
   MpdataTileInfo t;
-  rc = choose_tile(variant(), nx, nz, &t);
+  rc = choose_tile(variant(), ncrms, nx, nz, &t);
   if (rc) return rc;
   mpdata_plan* p = (mpdata_plan*)calloc(1, sizeof(mpdata_plan));
   if (!p) return set_err(MPDATA_EINVAL, "out of host memory");
@@ -369,6 +374,12 @@ int mpdata_set_tile(int tile) {
   const int prev = tile_override();
   g_tile = tile < 0 ? -1 : tile;
   return prev;
+}
+// Diagnostic builds (-DMPD2_STAMPS) write s_memtime/s_memrealtime stamps of wave 0 of
+// every workgroup into this device buffer; production builds ignore it.
+int mpdata_set_debug_buffer(void* dev_ptr) {
+  g_dbg = (unsigned long long*)dev_ptr;
+  return 0;
 }
 int mpdata_device_count(void) {
   int n = 0;

@@ -24,10 +24,16 @@
 //     of 3-slot rings indexed by (column mod 3) with the loop unrolled by 3, so
 //     no register-to-register rotation is executed;
 //   * HBM is read and written in rows that are contiguous along sl.  The 16
-//     instances of a workgroup give 128-byte rows; each step the workgroup
-//     loads the 3*nzm rows (f,u,w) of the next column cooperatively with lanes
-//     along sl, transposes them through LDS (row stride 17 doubles: conflict
-//     free both ways), and writes the finished column back the same way;
+//     instances of a workgroup give 128-byte rows.  The 3*nzm rows (f,u,w) of
+//     column q+3 are fetched while column q is computed, by LDS-DMA
+//     (buffer_load_dword ... lds: no VGPR staging, no ds_write), two rows per
+//     wave instruction, into a 4-column LDS ring; rows are XOR-swizzled on the
+//     SOURCE address so that the transposed read (lanes along k) is free of
+//     bank conflicts.  The finished column goes back through a padded LDS
+//     tile (row stride 17 doubles) and full-row stores.  Every step issues the
+//     same number of vector-memory operations per wave (1 store + 6 DMA), so
+//     one counted s_waitcnt vmcnt(14) + a raw s_barrier per step is the only
+//     synchronisation and three columns stay in flight across it;
 //   * irho, iadz, irhow, dd (:552-553,:565,:569) depend on (sl,k) only and are
 //     computed ONCE per lane, not once per column.
 //
@@ -52,7 +58,9 @@
 namespace MPDATA_NS {
 namespace v2 {
 
+#ifndef MPD2_G
 #define MPD2_G 16  // CRM instances per workgroup (128-byte rows)
+#endif
 #ifndef MPD2_USE_FULL
 #define MPD2_USE_FULL 0  // 1: condition-free steady-state body (higher register pressure)
 #endif
@@ -89,8 +97,32 @@ __device__ __forceinline__ double ratio(double n, double d) {
 #endif
 }
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// Buffer addressing for the row transfers: wave-uniform descriptor + per-lane
+// 32-bit byte offset (VGPR) + wave-uniform byte offset of the column (SGPR).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long long bytes) {
+  const long long lim = 0xFFFFFFFFll;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0,
+                                           (int)(unsigned)(bytes > lim ? lim : bytes), 0x00020000);
+}
+__device__ __forceinline__ double ld_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+#ifdef MPD2_ABL_NOMEM  // timing ablation only (wrong results)
+  return (double)(voff + soff);
+#endif
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
+#ifdef MPD2_ABL_NOMEM
+  if (v != 1.2345e300) return;
+#endif
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
+}
+
 // value of `v` held by the lane whose byte index is `addr` (= 4*lane)
 __device__ __forceinline__ double lane_get(int addr, double v) {
+#ifdef MPD2_ABL_NOPERM  // timing ablation only (wrong results)
+  return v + (double)addr;
+#endif
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_ds_bpermute(addr, lo);
   hi = __builtin_amdgcn_ds_bpermute(addr, hi);
@@ -100,13 +132,16 @@ __device__ __forceinline__ double lane_get(int addr, double v) {
 template <int LPS>
 struct TileV2 {
   static constexpr int SLP = 64 / LPS;         // instances per wave
-  static constexpr int NWV = MPD2_G / SLP;     // waves per workgroup
+  static constexpr int NWV = MPD2_G / SLP;     // waves per workgroup (= LPS/4)
   static constexpr int THREADS = 64 * NWV;     // = 16 * LPS
-  static constexpr int RS = MPD2_G + 1;        // LDS row stride in doubles
+  static constexpr int RS = MPD2_G + 1;        // out tile: LDS row stride in doubles
   static constexpr int NZM_MAX = LPS - 1;
-  static constexpr int IN_SLOT = 3 * NZM_MAX * RS;   // f,u,w rows of one column
+  static constexpr int NSLOT = 4;              // input ring: columns q .. q+3
+  static constexpr int ARR = LPS * MPD2_G;     // doubles of one array block (LPS rows x 16)
+  static constexpr int IN_SLOT = 3 * ARR;      // f,u,w rows of one column
   static constexpr int OUT_SLOT = NZM_MAX * RS;
-  static constexpr int LDS_DOUBLES = 2 * IN_SLOT + 2 * OUT_SLOT;
+  static constexpr int LDS_DOUBLES = NSLOT * IN_SLOT + 2 * OUT_SLOT;
+  static constexpr int VM_PER_STEP = 7;        // 1 store + 6 DMA per wave and step
 };
 
 // Rolling window: rings of 3 slots indexed by (column mod 3).
@@ -119,13 +154,13 @@ struct Window {
 };
 
 template <int LPS>
-__global__ void __launch_bounds__(16 * LPS, 4)
+__global__ void __launch_bounds__(MPD2_G * LPS, 4)
 mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   using T = TileV2<LPS>;
   constexpr int G = MPD2_G, RS = T::RS, SLP = T::SLP;
   __shared__ double lds[T::LDS_DOUBLES];
   double* const in_slot0 = lds;
-  double* const out_slot0 = lds + 2 * T::IN_SLOT;
+  double* const out_slot0 = lds + T::NSLOT * T::IN_SLOT;
 
   const int nx = a.nx, nz = a.nz, nzm = nz - 1;
   const long long ncrms = a.ncrms;
@@ -160,27 +195,92 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   const double IRHO = 1.0 / RHO;
   const double IADZ = 1.0 / adz_l;
   const double IRHOW = 1.0 / (rhow_l * adz_l);
-  const double DD = ((k == 1 || k == nzm) ? 2.0 : 1.0) * IADZ;  // 2./(kc-kb)/adz, exact
+  // :569  dd = 2./(kc-kb)/adz = (2 or 1)*(1/adz) exactly; the factor 2 is applied as an
+  // exponent step on dd*(...) (exact scaling, bit-identical)
+  const int dd_exp = (k == 1 || k == nzm) ? 1 : 0;
   const bool k_is_1 = k == 1;
 
-  // ---- transfer-side mapping: thread -> (row = level, instance) -------------
-  const int t_row = tid / G;  // level index k-1 of the row this thread moves
+  // ---- write-back mapping: thread -> (row = level, instance) -----------------
+  const int t_row = tid / G;  // level index k-1 of the row this thread stores
   const int t_sl = tid % G;
   const bool t_act = t_row < nzm;
   long long sl_t = sl_base + t_sl;
   const bool slt_ok = sl_t < ncrms;
   if (!slt_ok) sl_t = ncrms - 1;
   const int t_rowc = t_act ? t_row : 0;
-  // element offsets of (column index 0, this level, this instance)
-  const long long tf = sl_t + ncrms * (long long)(nx + 6) * t_rowc;
-  const long long tu = sl_t + ncrms * (long long)(nx + 5) * t_rowc;
-  const long long tw = sl_t + ncrms * (long long)(nx + 4) * t_rowc;
-  const int t_lds = t_rowc * RS + t_sl;          // position inside one array block of a slot
-  const int c_lds = (kl - 1) * RS + sl_l;        // compute-side read position
-  const bool t_st = t_act && slt_ok;
+  const int t_lds = t_rowc * RS + t_sl;  // position inside an out tile
+  // byte offset of (column index 0, this level, this instance); 32-bit: the host
+  // picks this kernel only when every array is smaller than 2^32 bytes.  Threads
+  // that own nothing get an out-of-range offset: the buffer range check drops
+  // their store, and every wave still issues the same number of stores.
+  const unsigned OOB = 0xFFFFFFF8u;
+  const unsigned tf = (t_act && slt_ok) ? (unsigned)((sl_t + ncrms * (long long)(nx + 6) * t_rowc) * 8) : OOB;
+  const unsigned colb = (unsigned)(ncrms * 8);  // bytes between columns
+  const __amdgpu_buffer_rsrc_t rsf = make_rsrc(f, ncrms * 8ll * (nx + 6) * nzm);
+  const __amdgpu_buffer_rsrc_t rsu = make_rsrc(a.u, ncrms * 8ll * (nx + 5) * nzm);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.w, ncrms * 8ll * (nx + 4) * nz);
 
-  double rf = 0, ru = 0, rw = 0;  // the column in flight
+  // ---- DMA mapping: one wave instruction moves two 128-byte rows (lanes 0-31:
+  //      row 2j, lanes 32-63: row 2j+1; 4 bytes per lane).  LDS image of a column:
+  //      [array][row][16 doubles], double (row, sl) stored at position
+  //      sl ^ ((row>>1) & 15): the swizzle is applied to the SOURCE address.
+  const int np = (nzm + 1) >> 1;  // row pairs per array
+  unsigned vdf[2], vdu[2], vdw[2];  // per-lane source byte offsets of the wave's two pairs
+  int jd[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int j = min(wave + it * T::NWV, np - 1);  // (a clamped duplicate rewrites the same bytes)
+    jd[it] = j;
+    const int row = min(2 * j + (lane >> 5), nzm - 1);
+    const int p = (lane & 31) >> 1;
+    long long sl_d = sl_base + (p ^ (j & 15));
+    if (sl_d >= ncrms) sl_d = ncrms - 1;
+    const unsigned part = (lane & 1) * 4;
+    vdf[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 6) * row) * 8) + part;
+    vdu[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 5) * row) * 8) + part;
+    vdw[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 4) * row) * 8) + part;
+  }
+  // compute-side read position inside one array block of a slot
+  const int c_lds = (kl - 1) * G + (sl_l ^ (((kl - 1) >> 1) & 15));
 
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  // all DMA of column `col` into its ring slot (6 instructions per wave)
+  auto dma_col = [&](const int col) __attribute__((always_inline)) {
+    const unsigned cf = colb * (unsigned)(min(max(col, -2), nx + 3) + 2);
+    const unsigned cu = colb * (unsigned)(min(max(col, -1), nx + 3) + 1);
+    const unsigned cw = colb * (unsigned)(min(max(col, -1), nx + 2) + 1);
+    double* slot = in_slot0 + (col & (T::NSLOT - 1)) * T::IN_SLOT;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      double* d = slot + jd[it] * 2 * G;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, 0);
+    }
+  };
+
+#ifdef MPD2_STAMPS
+  // diagnostic build: wave 0 of each workgroup records (shader clock, 100 MHz real time)
+  // at kernel start/end and the shader clock at 4 points of every step
+  unsigned long long* const dbgw = a.dbg ? a.dbg + (size_t)blockIdx.x * 256 : nullptr;
+  const bool stamp = dbgw && wave == 0 && blockIdx.y == 0;
+  int stamp_i = 4;
+  auto STAMP = [&]() __attribute__((always_inline)) {
+    if (stamp && stamp_i < 256) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      if (lane == 0) dbgw[stamp_i] = t;
+      ++stamp_i;
+    }
+  };
+  if (stamp) {
+    unsigned long long t0, r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+    if (lane == 0) { dbgw[0] = t0; dbgw[1] = r0; }
+  }
+#else
+#define STAMP() ((void)0)
+#endif
   Window S;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -198,32 +298,39 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr int C0 = PH, C1 = (PH + 2) % 3, C2 = (PH + 1) % 3, C3 = PH;  // slots of q, q-1, q-2, q-3
 
-    __syncthreads();  // column q staged; finished column q-4 in the out slot
+    // column q landed (this wave's DMA of it is 2 steps = 14 vector-memory ops
+    // old), out tile of column q-4 written: then everyone's are, after the barrier
+    STAMP();
+    asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+    STAMP();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    STAMP();
 
-    // ---- next column into flight (columns clamped into each array's range;
-    //      a clamped copy is never used by a valid result)
-    if (FULL || q + 1 <= nx + 3) {
-      if (t_act) {
-        const int q1 = q + 1;
-        const int cf = FULL ? q1 + 2 : min(max(q1, -2), nx + 3) + 2;
-        const int cu = FULL ? q1 + 1 : min(max(q1, -1), nx + 3) + 1;
-        const int cw = FULL ? q1 + 1 : min(max(q1, -1), nx + 2) + 1;
-        rf = f[tf + ncrms * (long long)cf];
-        ru = a.u[tu + ncrms * (long long)cu];
-        rw = a.w[tw + ncrms * (long long)cw];
-      }
+    // ---- write back the column finished in the previous step (n = q-4); an
+    //      inactive step stores out of range (dropped), the op count stays fixed
+    {
+      const bool act = q - 4 >= -1 && q - 4 <= nx + 2;
+#ifdef MPD2_ABL_NOSTORE
+      st_row(rsf, OOB, colb * (unsigned)max(q - 4 + 2, 0),
+#else
+      st_row(rsf, (FULL || act) ? tf : OOB, colb * (unsigned)max(q - 4 + 2, 0),
+#endif
+             out_slot0[((q - 1) & 1) * T::OUT_SLOT + t_lds]);
     }
-    // ---- write back the column finished in the previous step (n = q-4) ------
-    if (FULL || (q - 4 >= -1 && q - 4 <= nx + 2)) {
-      if (t_st) f[tf + ncrms * (long long)(q - 4 + 2)] = out_slot0[((q - 1) & 1) * T::OUT_SLOT + t_lds];
-    }
+    // ---- column q+3 into flight -------------------------------------------------
+    dma_col(q + 3);
 
     // ---- this column, transposed: lanes along k -------------------------------
-    const double* s = in_slot0 + (q & 1) * T::IN_SLOT;
+    const double* s = in_slot0 + (q & (T::NSLOT - 1)) * T::IN_SLOT;
     const double f0q = s[c_lds];
-    const double uq = s[T::NZM_MAX * RS + c_lds];
-    const double wq = lvl_ok ? s[2 * T::NZM_MAX * RS + c_lds] : 0.0;  // ghost level: w = 0
+    const double uq = s[T::ARR + c_lds];
+    const double wq = lvl_ok ? s[2 * T::ARR + c_lds] : 0.0;  // ghost level: w = 0
 
+#ifdef MPD2_ABL_NOCOMPUTE  // timing ablation only: data movement without the arithmetic
+    if (q - 3 >= -1 && q - 3 <= nx + 2 && lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = f0q + uq + wq;
+    return;
+#endif
     const double f0d = lane_get(a_dn, f0q);
     const double f0u = lane_get(a_upc, f0q);
     const double F0p = S.F0[C1];
@@ -269,12 +376,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     S.PW[C0] = wq + wu;
     S.WR[C0] = wq;
 
+    STAMP();
     // ================= stage B/C ===============================================
     double U2_1 = 0.0, W2_2 = 0.0, MXN_2 = 0.0, MNN_2 = 0.0;
     if (FULL || (q >= 1 && q <= nx + 3)) {
       {  // :571-573, column q-1
         const double ad = andiff(S.F1[C2], f1_1, S.UR[C1], IRHO);
-        const double x = DD * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1);
+        const double x = __builtin_ldexp(IADZ * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1), dd_exp);
         U2_1 = ad - across(x, S.UR[C1], S.SW[C1]) * IRHO;
       }
       if (FULL || q >= 2) {  // column q-2
@@ -325,15 +433,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     S.U3[C2] = U3_2;
     S.DW3[C2] = DW3_2;
 
-    // ---- stage the column that was in flight ----------------------------------
-    if (FULL || q + 1 <= nx + 3) {
-      if (t_act) {
-        double* d = in_slot0 + ((q + 1) & 1) * T::IN_SLOT;
-        d[t_lds] = rf;
-        d[T::NZM_MAX * RS + t_lds] = ru;
-        d[2 * T::NZM_MAX * RS + t_lds] = rw;
-      }
-    }
   };
 
   using P0 = std::integral_constant<int, 0>;
@@ -343,15 +442,12 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   using Part = std::false_type;
 
   const int q_first = -2;
-  // first column
-  if (t_act) {
-    rf = f[tf];
-    ru = a.u[tu];
-    rw = a.w[tw];
-    double* d = in_slot0;  // slot (q_first & 1) == 0
-    d[t_lds] = rf;
-    d[T::NZM_MAX * RS + t_lds] = ru;
-    d[2 * T::NZM_MAX * RS + t_lds] = rw;
+  // columns -2, -1, 0 into flight, each behind a dropped store so that the
+  // counted wait of the first steps sees the steady-state op pattern
+#pragma unroll
+  for (int c = q_first; c < q_first + 3; ++c) {
+    st_row(rsf, OOB, 0, 0.0);
+    dma_col(c);
   }
 
   // q advances by 3 per trip so that the ring phase is a compile-time constant.
@@ -370,6 +466,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     }
   }
 
+#ifdef MPD2_STAMPS
+  if (stamp) {
+    unsigned long long t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+    if (lane == 0) { dbgw[2] = t1; dbgw[3] = r1; }
+  }
+#endif
   if (lvl_ok && slc_ok) flux[sl_c + ncrms * (long long)(k - 1)] = S1 + S3;  // :541-547, :624
 }
 

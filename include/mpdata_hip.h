@@ -109,6 +109,7 @@ int mpdata_unpack_shard_device(double* full, const double* shard, int64_t rows, 
 int mpdata_set_variant(int variant);      /* MPDATA_VARIANT_*; returns previous */
 int mpdata_get_variant(void);
 int mpdata_set_tile(int tile);            /* kernel tiling id; -1 = default */
+int mpdata_set_debug_buffer(void* dev_ptr); /* diagnostic builds only: clock-stamp buffer */
 int mpdata_device_count(void);
 int64_t mpdata_algorithmic_bytes(int64_t ncrms, int nx, int nz, int ntracers);
 const char* mpdata_last_error(void);
