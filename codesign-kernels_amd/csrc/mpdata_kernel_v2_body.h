@@ -61,6 +61,12 @@ namespace v2 {
 #ifndef MPD2_G
 #define MPD2_G 16  // CRM instances per workgroup (128-byte rows)
 #endif
+#ifndef MPD2_AUX_LD
+#define MPD2_AUX_LD 0  // cache-policy bits of the DMA loads (2 = nt)
+#endif
+#ifndef MPD2_AUX_ST
+#define MPD2_AUX_ST 0  // ... of the row stores
+#endif
 #ifndef MPD2_USE_FULL
 #define MPD2_USE_FULL 0  // 1: condition-free steady-state body (higher register pressure)
 #endif
@@ -115,7 +121,7 @@ __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 #ifdef MPD2_ABL_NOMEM
   if (v != 1.2345e300) return;
 #endif
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, MPD2_AUX_ST);
 }
 
 // value of `v` held by the lane whose byte index is `addr` (= 4*lane)
@@ -253,9 +259,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       double* d = slot + jd[it] * 2 * G;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, MPD2_AUX_LD);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, MPD2_AUX_LD);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, MPD2_AUX_LD);
     }
   };
 

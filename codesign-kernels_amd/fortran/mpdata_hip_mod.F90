@@ -1,0 +1,136 @@
+!> Fortran face of libmpdata_hip.so (include/mpdata_hip.h): the thin
+!! ISO_C_BINDING layer and the drop-in `advect_scalar2D(f,u,w,rho,rhow,flux)`.
+!!
+!! The dummy-argument list and the array shapes are those of the reference's
+!! advect_scalar2D_cpu / _openacc_1 / _openacc_2
+!! (mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:477-484, :247, :72);
+!! sizes and adz come from module mpdata_grid, where the reference takes them
+!! by host association (:7-30).  The binding style (bind(C,name=..), scalars by
+!! value, arrays as bare pointers, persistent device state behind the library)
+!! follows the reference's own Fortran->C++ precedent, nested_loops/cke_mod.F90:4-50.
+!! There is no CPU implementation behind this interface: a failing HIP call
+!! stops the program.
+module mpdata_hip_mod
+  use iso_c_binding
+  use mpdata_grid
+  implicit none
+  private
+  public :: advect_scalar2D, advect_resident_begin, advect_resident_run, advect_resident_end
+  public :: mpdata_set_variant, mpdata_check
+
+  interface
+    integer(c_int) function mpdata_advect_scalar2d_c(ncrms, nx, nz, ntracers, f, u, w, rho, rhow, adz, flux) &
+        bind(C, name="mpdata_advect_scalar2d")
+      import :: c_int, c_int64_t, c_double
+      integer(c_int64_t), value :: ncrms
+      integer(c_int), value :: nx, nz, ntracers
+      real(c_double) :: f(*), flux(*)
+      real(c_double), intent(in) :: u(*), w(*), rho(*), rhow(*), adz(*)
+    end function
+    integer(c_int) function mpdata_plan_create_c(ncrms, nx, nz, ntracers, plan) bind(C, name="mpdata_plan_create")
+      import :: c_int, c_int64_t, c_ptr
+      integer(c_int64_t), value :: ncrms
+      integer(c_int), value :: nx, nz, ntracers
+      type(c_ptr) :: plan
+    end function
+    integer(c_int) function mpdata_plan_upload_c(plan, f, u, w, rho, rhow, adz, flux) bind(C, name="mpdata_plan_upload")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: plan
+      real(c_double), intent(in) :: f(*), u(*), w(*), rho(*), rhow(*), adz(*), flux(*)
+    end function
+    integer(c_int) function mpdata_plan_run_c(plan) bind(C, name="mpdata_plan_run")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: plan
+    end function
+    integer(c_int) function mpdata_plan_sync_c(plan) bind(C, name="mpdata_plan_sync")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: plan
+    end function
+    integer(c_int) function mpdata_plan_download_c(plan, f, flux) bind(C, name="mpdata_plan_download")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: plan
+      real(c_double) :: f(*), flux(*)
+    end function
+    integer(c_int) function mpdata_plan_last_kernel_ms_c(plan, ms) bind(C, name="mpdata_plan_last_kernel_ms")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: plan
+      real(c_double) :: ms
+    end function
+    integer(c_int) function mpdata_plan_destroy_c(plan) bind(C, name="mpdata_plan_destroy")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: plan
+    end function
+    integer(c_int) function mpdata_set_variant(variant) bind(C, name="mpdata_set_variant")
+      import :: c_int
+      integer(c_int), value :: variant
+    end function
+    type(c_ptr) function mpdata_last_error_c() bind(C, name="mpdata_last_error")
+      import :: c_ptr
+    end function
+  end interface
+
+  type(c_ptr), save :: resident_plan = c_null_ptr
+
+contains
+
+  !> `error stop` with the library's message when a C-ABI call failed
+  !! (the reference has no error path at all; a failure there is a crash).
+  subroutine mpdata_check(rc, what)
+    integer(c_int), intent(in) :: rc
+    character(*), intent(in) :: what
+    character(kind=c_char), pointer :: msg(:)
+    integer :: n
+    if (rc == 0) return
+    call c_f_pointer(mpdata_last_error_c(), msg, [512])
+    n = 1
+    do while (n < 512 .and. msg(n) /= c_null_char)
+      n = n + 1
+    end do
+    write(*,*) 'libmpdata_hip: ', what, ' failed, rc=', rc, ': ', msg(1:n-1)
+    error stop 1
+  end subroutine mpdata_check
+
+  !> Drop-in replacement of `call advect_scalar2D_openacc_N(f,u,w,rho,rhow,flux)`
+  !! (reference :53, :57): synchronous, host arrays, transfers included (the
+  !! reference's `!$acc update device/host`, :107 and :241).
+  subroutine advect_scalar2D(f, u, w, rho, rhow, flux)
+    real(rp), intent(inout) :: f    (nslices, -2:nx+3, 1, nzm, ntracers)
+    real(rp), intent(in   ) :: u    (nslices, -1:nx+3, 1, nzm)
+    real(rp), intent(in   ) :: w    (nslices, -1:nx+2, 1, nz )
+    real(rp), intent(in   ) :: rho  (nslices, nzm)
+    real(rp), intent(in   ) :: rhow (nslices, nz )
+    real(rp), intent(inout) :: flux (nslices, nz, ntracers)   ! level nz is left as it came (reference :541,:624)
+    call mpdata_check(mpdata_advect_scalar2d_c(nslices, nx, nz, ntracers, f, u, w, rho, rhow, adz, flux), &
+                      'mpdata_advect_scalar2d')
+  end subroutine advect_scalar2D
+
+  !> Device-resident form = the reference's timed region (:105-110, :237-242):
+  !! begin = `enter data` + `update device`; run = the kernels + `wait`;
+  !! end = `update host`.
+  subroutine advect_resident_begin(f, u, w, rho, rhow, flux)
+    real(rp), intent(in) :: f(nslices, -2:nx+3, 1, nzm, ntracers), u(nslices, -1:nx+3, 1, nzm), w(nslices, -1:nx+2, 1, nz)
+    real(rp), intent(in) :: rho(nslices, nzm), rhow(nslices, nz), flux(nslices, nz, ntracers)
+    call mpdata_check(mpdata_plan_create_c(nslices, nx, nz, ntracers, resident_plan), 'mpdata_plan_create')
+    call mpdata_check(mpdata_plan_upload_c(resident_plan, f, u, w, rho, rhow, adz, flux), 'mpdata_plan_upload')
+  end subroutine advect_resident_begin
+
+  subroutine advect_resident_run(kernel_ms)
+    real(rp), intent(out), optional :: kernel_ms
+    real(c_double) :: ms
+    call mpdata_check(mpdata_plan_run_c(resident_plan), 'mpdata_plan_run')
+    call mpdata_check(mpdata_plan_sync_c(resident_plan), 'mpdata_plan_sync')
+    if (present(kernel_ms)) then
+      call mpdata_check(mpdata_plan_last_kernel_ms_c(resident_plan, ms), 'mpdata_plan_last_kernel_ms')
+      kernel_ms = ms
+    end if
+  end subroutine advect_resident_run
+
+  subroutine advect_resident_end(f, flux)
+    real(rp), intent(out) :: f(nslices, -2:nx+3, 1, nzm, ntracers)
+    real(rp), intent(inout) :: flux(nslices, nz, ntracers)
+    call mpdata_check(mpdata_plan_download_c(resident_plan, f, flux), 'mpdata_plan_download')
+    call mpdata_check(mpdata_plan_destroy_c(resident_plan), 'mpdata_plan_destroy')
+    resident_plan = c_null_ptr
+  end subroutine advect_resident_end
+
+end module mpdata_hip_mod

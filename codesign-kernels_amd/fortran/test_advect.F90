@@ -1,0 +1,127 @@
+!> Driver of the MI355X build: the role of the reference's `program test_advect`
+!! (mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:3-68, :645-683).
+!!
+!!   ./advect [ncrms nx nz [dist [variant [dumpfile]]]]
+!!
+!! Sequence (reference :48-50): init() -> advect_scalar2D(f,u,w,rho,rhow,flux)
+!! -> save().  Sizes are run-time (the reference fixes them at compile time,
+!! :7-9); inputs come from a portable seeded generator instead of the
+!! compiler's random_number (:649-660), in the same fill order.  Timing lines
+!! keep the reference's format (:640, :239).  The reference's compare() step
+!! (:679-683) needs the CPU routine's result; this program does not contain a
+!! CPU advection routine -- tests/test_fortran_driver.py runs it, reads the
+!! dump written by save() and makes that comparison against the oracle.
+program test_advect
+  use iso_c_binding
+  use mpdata_grid
+  use mpdata_hip_mod
+  implicit none
+
+  real(rp), allocatable :: f(:,:,:,:,:), u(:,:,:,:), w(:,:,:,:), rho(:,:), rhow(:,:), flux(:,:,:)
+  real(rp), allocatable :: f_in(:,:,:,:,:)
+  integer(c_int64_t) :: n_arg
+  integer :: nx_arg, nz_arg, dist, variant, rc
+  character(len=512) :: arg, dumpfile
+  integer(8) :: t1, t2, tr
+  real(rp) :: kms
+
+  n_arg = 64; nx_arg = 32; nz_arg = 28; dist = 1; variant = 0; dumpfile = ''
+  if (command_argument_count() >= 3) then
+    call get_command_argument(1, arg); read(arg, *) n_arg
+    call get_command_argument(2, arg); read(arg, *) nx_arg
+    call get_command_argument(3, arg); read(arg, *) nz_arg
+  end if
+  if (command_argument_count() >= 4) then
+    call get_command_argument(4, arg); read(arg, *) dist
+  end if
+  if (command_argument_count() >= 5) then
+    call get_command_argument(5, arg); read(arg, *) variant
+  end if
+  if (command_argument_count() >= 6) call get_command_argument(6, dumpfile)
+
+  call grid_set(n_arg, nx_arg, nz_arg)
+  allocate(f(nslices, -2:nx+3, 1, nzm, 1), u(nslices, -1:nx+3, 1, nzm), w(nslices, -1:nx+2, 1, nz))
+  allocate(rho(nslices, nzm), rhow(nslices, nz), flux(nslices, nz, 1))
+  rc = mpdata_set_variant(int(variant, c_int))
+
+  ! ---- the drop-in call: host arrays, transfers inside (reference :53 pattern)
+  call init()
+  allocate(f_in, source=f)
+  call system_clock(t1)
+  call advect_scalar2D(f, u, w, rho, rhow, flux)
+  call system_clock(t2, tr)
+  write(*,*) 'HIP Timing (call, transfers included): ', dble(t2-t1)/dble(tr)
+  call save()
+
+  ! ---- device-resident: the reference's timed region (kernels only, :110-:238)
+  call init()
+  call advect_resident_begin(f, u, w, rho, rhow, flux)
+  call advect_resident_run()            ! warm-up (the reference's first OpenACC call pays it too)
+  call advect_resident_end(f, flux)
+  call init()
+  call advect_resident_begin(f, u, w, rho, rhow, flux)
+  call system_clock(t1)
+  call advect_resident_run(kms)
+  call system_clock(t2, tr)
+  write(*,*) 'HIP Timing: ', dble(t2-t1)/dble(tr)
+  write(*,*) 'HIP kernel (hipEvent) seconds: ', kms*1.0e-3_rp
+  call advect_resident_end(f, flux)
+  write(*,*) 'cell updates per call: ', nslices*int(nx,8)*int(nzm,8)
+  write(*,*) 'checksum f   : ', sum(f)
+  write(*,*) 'checksum flux: ', sum(flux(:,1:nzm,:))
+
+contains
+
+  !> splitmix64-style counter generator, bit-identical to
+  !! mpdata_fill_synthetic_device / the test oracle's generator: element j
+  !! (0-based, Fortran order) of array `sid` = top53(mix(seed + sid*K + (j+1)*G)) * 2^-53 + shift
+  subroutine fill(a, n, sid, seed, dist)
+    integer(8), intent(in) :: n
+    real(rp), intent(out) :: a(n)
+    integer, intent(in) :: sid, dist
+    integer(8), intent(in) :: seed
+    integer(8), parameter :: golden = int(z'9E3779B97F4A7C15', 8), ksid = int(z'D1B54A32D192ED03', 8)
+    integer(8), parameter :: m1 = int(z'BF58476D1CE4E5B9', 8), m2 = int(z'94D049BB133111EB', 8)
+    integer(8) :: j, z, base
+    real(rp) :: shift
+    shift = 0._rp
+    if (dist == 1) then
+      if (sid == 2 .or. sid == 3) shift = -0.5_rp
+      if (sid == 0 .or. sid == 4 .or. sid == 5) shift = 0.5_rp
+    else if (dist == 3) then
+      if (sid == 2 .or. sid == 3) shift = -0.5_rp
+    end if
+    base = seed + int(sid, 8) * ksid
+    do j = 1, n
+      z = base + j * golden
+      z = ieor(z, shiftr(z, 30)) * m1
+      z = ieor(z, shiftr(z, 27)) * m2
+      z = ieor(z, shiftr(z, 31))
+      a(j) = real(shiftr(z, 11), rp) * 2._rp**(-53) + shift
+    end do
+  end subroutine fill
+
+  !> reference :645-665: same arrays, same order (adz,f,u,w,rho,rhow,flux)
+  subroutine init()
+    integer(8), parameter :: seed = 100_8
+    call fill(adz,  size(adz, kind=8),  0, seed, dist)
+    call fill(f,    size(f, kind=8),    1, seed, dist)
+    call fill(u,    size(u, kind=8),    2, seed, dist)
+    call fill(w,    size(w, kind=8),    3, seed, dist)
+    call fill(rho,  size(rho, kind=8),  4, seed, dist)
+    call fill(rhow, size(rhow, kind=8), 5, seed, dist)
+    call fill(flux, size(flux, kind=8), 6, seed, dist)
+  end subroutine init
+
+  !> reference :668-676 keeps copies for compare(); here the result is written
+  !! out (stream binary: f then flux) when a dump file was named
+  subroutine save()
+    integer :: iu
+    if (len_trim(dumpfile) == 0) return
+    open(newunit=iu, file=trim(dumpfile), access='stream', form='unformatted', status='replace')
+    write(iu) f
+    write(iu) flux
+    close(iu)
+  end subroutine save
+
+end program test_advect
