@@ -68,7 +68,7 @@ namespace v2 {
 #define MPD2_AUX_ST 0  // ... of the row stores
 #endif
 #ifndef MPD2_USE_FULL
-#define MPD2_USE_FULL 0  // 1: condition-free steady-state body (higher register pressure)
+#define MPD2_USE_FULL 1  // 1: condition-free body for the steady-state columns
 #endif
 
 __device__ __forceinline__ double dmax(double x, double y) { return __builtin_fmax(x, y); }
@@ -460,12 +460,21 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   // Steps always run in whole triples (no step is skipped, so no ring slot stays
   // live across the loop edge); the march needs q up to nx+6 (write-back of the
   // last halo column), any further step of the last triple does nothing.
-  for (int q = q_first; q <= nx + 6; q += 3) {
-    if (MPD2_USE_FULL && q >= 4 && q + 2 <= nx) {
+  {
+    int q = q_first;
+    for (; q < 4; q += 3) {  // columns -2 .. 3: pipeline fill
+      step(P0{}, Part{}, q);
+      step(P1{}, Part{}, q + 1);
+      step(P2{}, Part{}, q + 2);
+    }
+#if MPD2_USE_FULL
+    for (; q + 2 <= nx; q += 3) {  // steady state: every stage active, no conditions
       step(P0{}, Full{}, q);
       step(P1{}, Full{}, q + 1);
       step(P2{}, Full{}, q + 2);
-    } else {
+    }
+#endif
+    for (; q <= nx + 6; q += 3) {  // remaining columns and pipeline drain
       step(P0{}, Part{}, q);
       step(P1{}, Part{}, q + 1);
       step(P2{}, Part{}, q + 2);
