@@ -67,6 +67,9 @@ namespace v2 {
 #ifndef MPD2_AUX_ST
 #define MPD2_AUX_ST 0  // ... of the row stores
 #endif
+#ifndef MPD2_DPP
+#define MPD2_DPP 1  // vertical neighbours by DPP moves (1) or ds_bpermute (0)
+#endif
 #ifndef MPD2_USE_FULL
 #define MPD2_USE_FULL 1  // 1: condition-free body for the steady-state columns
 #endif
@@ -133,6 +136,46 @@ __device__ __forceinline__ double lane_get(int addr, double v) {
   lo = __builtin_amdgcn_ds_bpermute(addr, lo);
   hi = __builtin_amdgcn_ds_bpermute(addr, hi);
   return __hiloint2double(hi, lo);
+}
+
+// ---- vertical neighbours by DPP (register crossbar in the VALU) ---------------
+// LDS-crossbar permutes (ds_bpermute) cost no VALU slot but ~5 LDS cycles per
+// CU each and, measured with in-kernel clock stamps, enough power that the chip
+// drops its clock by ~15 %; DPP moves are two 32-bit VALU passes per double.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov(double old, double src) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, BANK_MASK, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
+}
+#define MPD_DPP_ROW_SHR1 0x111
+#define MPD_DPP_WAVE_SHL1 0x130
+#define MPD_DPP_WAVE_SHR1 0x138
+
+// value of lane-1 (level kb); lanes with no source keep their own value
+template <int LPS>
+__device__ __forceinline__ double shift_dn_clamped(double x, bool k_is_1) {
+  if constexpr (LPS == 64) {
+    return dpp_mov<MPD_DPP_WAVE_SHR1, 0xF, 0xF>(x, x);            // lane 0 keeps x: kb clamp at k = 1
+  } else if constexpr (LPS == 16) {
+    return dpp_mov<MPD_DPP_ROW_SHR1, 0xF, 0xF>(x, x);             // every 16-lane row starts an instance
+  } else if constexpr (LPS == 32) {
+    double r = dpp_mov<MPD_DPP_ROW_SHR1, 0xF, 0xF>(x, x);         // lanes 0,16,32,48 keep x
+    return dpp_mov<MPD_DPP_WAVE_SHR1, 0xA, 0x1>(r, x);            // lanes 16-19, 48-51 <- lane-1
+  } else {
+    double r = dpp_mov<MPD_DPP_WAVE_SHR1, 0xF, 0xF>(x, x);
+    return k_is_1 ? x : r;
+  }
+}
+__device__ __forceinline__ double shift_dn(double x) { return dpp_mov<MPD_DPP_WAVE_SHR1, 0xF, 0xF>(x, x); }
+// value of lane+1 (level k+1); the last lane keeps its own value
+__device__ __forceinline__ double shift_up(double x) { return dpp_mov<MPD_DPP_WAVE_SHL1, 0xF, 0xF>(x, x); }
+// ... clamped at the top level (kc = min(nzm,k+1)).  The move is executed by ALL lanes
+// before the select: under a divergent EXEC mask a DPP source lane that is switched off
+// counts as missing and the reader silently keeps its own value.
+__device__ __forceinline__ double shift_up_clamped(double x, bool top) {
+  const double t = shift_up(x);
+  return top ? x : t;
 }
 
 template <int LPS>
@@ -205,6 +248,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   // exponent step on dd*(...) (exact scaling, bit-identical)
   const int dd_exp = (k == 1 || k == nzm) ? 1 : 0;
   const bool k_is_1 = k == 1;
+  const bool k_ge_nzm = k >= nzm;
 
   // ---- write-back mapping: thread -> (row = level, instance) -----------------
   const int t_row = tid / G;  // level index k-1 of the row this thread stores
@@ -337,8 +381,19 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     if (q - 3 >= -1 && q - 3 <= nx + 2 && lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = f0q + uq + wq;
     return;
 #endif
-    const double f0d = lane_get(a_dn, f0q);
-    const double f0u = lane_get(a_upc, f0q);
+#if MPD2_DPP
+#define DN_C(x) shift_dn_clamped<LPS>((x), k_is_1)
+#define DN_P(x) shift_dn(x)
+#define UP_C(x) shift_up_clamped((x), k_ge_nzm)
+#define UP_G(x) shift_up(x)
+#else
+#define DN_C(x) lane_get(a_dn, (x))
+#define DN_P(x) lane_get(a_dn, (x))
+#define UP_C(x) lane_get(a_upc, (x))
+#define UP_G(x) lane_get(a_upg, (x))
+#endif
+    const double f0d = DN_C(f0q);
+    const double f0u = UP_C(f0q);
     const double F0p = S.F0[C1];
 
     // ================= stage A =================================================
@@ -349,13 +404,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
       U1q = dmax(0.0, uq) * F0p + dmin(0.0, uq) * f0q;  // :532
       if (FULL || q <= nx + 2) {
         const double W1q = dmax(0.0, wq) * f0d + dmin(0.0, wq) * f0q;  // :537
-        DW1q = lane_get(a_upg, W1q) - W1q;
+        DW1q = UP_G(W1q) - W1q;
         if (FULL || (q >= 1 && q <= nx)) S1 = S1 + W1q;  // :545
       }
       if (FULL || q >= 0) {
         f1_1 = F0p - ((U1q - S.U1[C1]) + S.DW1[C1] * IADZ) * IRHO;  // :557, column q-1
-        F1D_1 = lane_get(a_dn, f1_1);
-        F1U_1 = lane_get(a_upc, f1_1);
+        F1D_1 = DN_C(f1_1);
+        F1U_1 = UP_C(f1_1);
         MX0_1 = dmax(S.PMX[C1], f0q);  // :521-522 complete for column q-1
         MN0_1 = dmin(S.PMN[C1], f0q);
       }
@@ -373,11 +428,11 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     S.F0[C0] = f0q;
 
     // u / w sums for the antidiffusive cross terms (:573, :582), reference order
-    const double ud = lane_get(a_dn, uq);
+    const double ud = DN_P(uq);
     S.SU[C1] = S.UD[C1] + S.UR[C1] + uq + ud;  // u(i,kb)+u(i,k)+u(ic,k)+u(ic,kb), i = q-1
     S.UR[C0] = uq;
     S.UD[C0] = ud;
-    const double wu = lane_get(a_upc, wq);
+    const double wu = UP_C(wq);
     S.SW[C0] = S.PW[C1] + wq + wu;             // w(ib,k)+w(ib,kc)+w(i,k)+w(i,kc), i = q
     S.PW[C0] = wq + wu;
     S.WR[C0] = wq;
@@ -398,7 +453,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
           const double v = ad - across(x, S.WR[C2], S.SU[C2]) * IRHO;
           W2_2 = k_is_1 ? 0.0 : v;
         }
-        const double W2u = lane_get(a_upc, W2_2);
+        const double W2u = UP_C(W2_2);
         // :596-597
         const double mx1 = dmax(dmax(dmax(dmax(dmax(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MX0[C2]);
         const double mn1 = dmin(dmin(dmin(dmin(dmin(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MN0[C2]);
@@ -419,12 +474,12 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
       U3_2 = pp(S.U2[C2]) * dmin(dmin(1.0, MXN_2), S.MNN[C3]) -
              pn(S.U2[C2]) * dmin(dmin(1.0, S.MXN[C3]), MNN_2);  // :618
       if (FULL || q <= nx + 2) {
-        const double mxd = lane_get(a_dn, MXN_2);
-        const double mnd = lane_get(a_dn, MNN_2);
+        const double mxd = DN_C(MXN_2);
+        const double mnd = DN_C(MNN_2);
         const double W3 = pp(W2_2) * dmin(dmin(1.0, MXN_2), mnd) -
                           pn(W2_2) * dmin(dmin(1.0, mxd), MNN_2);  // :623
         S3 = S3 + W3;  // :624
-        DW3_2 = lane_get(a_upg, W3) - W3;
+        DW3_2 = UP_G(W3) - W3;
       }
     }
     {
