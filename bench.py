@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--nx", type=int, default=32)
     ap.add_argument("--nz", type=int, default=28)
     ap.add_argument("--tracers", type=int, default=1)
-    ap.add_argument("--variant", choices=["exact", "fast"], default=os.environ.get("MPDATA_VARIANT", "exact"))
+    ap.add_argument("--variant", choices=["exact", "fast"], default=os.environ.get("MPDATA_VARIANT", "fast"),
+                    help="fast: FMA contraction (max|df| < 1e-12 vs the reference, tests/test_hip_parity.py); "
+                         "exact: bit-identical f")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--dist", type=int, default=1, help="1 conditioned, 2 reference-raw, 3 raw-signed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
