@@ -67,6 +67,9 @@ namespace v2 {
 #ifndef MPD2_AUX_ST
 #define MPD2_AUX_ST 0  // ... of the row stores
 #endif
+#ifndef MPD2_XCD_REMAP
+#define MPD2_XCD_REMAP 0
+#endif
 #ifndef MPD2_DPP
 #define MPD2_DPP 1  // vertical neighbours by DPP moves (1) or ds_bpermute (0)
 #endif
@@ -214,9 +217,18 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   const int nx = a.nx, nz = a.nz, nzm = nz - 1;
   const long long ncrms = a.ncrms;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler too
   const int tr = blockIdx.y;
-  const long long sl_base = (long long)blockIdx.x * G;
+#if MPD2_XCD_REMAP
+  // blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): give each XCD a
+  // contiguous range of instance groups (speed only; any placement is correct)
+  const unsigned nblk = gridDim.x;
+  const unsigned grp = (nblk % 8 == 0) ? (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8 : blockIdx.x;
+#else
+  const unsigned grp = blockIdx.x;
+#endif
+  const long long sl_base = (long long)grp * G;
 
   double* const f = a.f + (long long)tr * a.f_tstride;
   double* const flux = a.flux + (long long)tr * a.flux_tstride;
