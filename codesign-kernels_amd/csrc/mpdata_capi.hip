@@ -111,6 +111,7 @@ int validate(int64_t ncrms, int nx, int nz, int ntracers) {
   if ((double)ncrms * (nx + 8) * 8.0 >= 2147483648.0)
     return set_err(MPDATA_EUNSUPPORTED, "ncrms*(nx+8)*8 must be < 2^31 bytes per k-plane");
   if (ntracers > 65535) return set_err(MPDATA_EUNSUPPORTED, "ntracers > 65535");
+  if ((ncrms + 15) / 16 > 65535) return set_err(MPDATA_EUNSUPPORTED, "ncrms > 16*65535 per call");
   return 0;
 }
 

@@ -219,14 +219,17 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler too
-  const int tr = blockIdx.y;
+  // grid = (tracers, instance groups): tracer is the FASTEST block index, so the
+  // workgroups that share the same rows of u,w,rho,rhow,adz are dispatched together and
+  // all but the first read them from the L2 / Infinity Cache instead of HBM
+  const int tr = blockIdx.x;
 #if MPD2_XCD_REMAP
   // blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): give each XCD a
   // contiguous range of instance groups (speed only; any placement is correct)
-  const unsigned nblk = gridDim.x;
-  const unsigned grp = (nblk % 8 == 0) ? (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8 : blockIdx.x;
+  const unsigned nblk = gridDim.y;
+  const unsigned grp = (nblk % 8 == 0) ? (blockIdx.y % 8) * (nblk / 8) + blockIdx.y / 8 : blockIdx.y;
 #else
-  const unsigned grp = blockIdx.x;
+  const unsigned grp = blockIdx.y;
 #endif
   const long long sl_base = (long long)grp * G;
 
@@ -324,8 +327,8 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 #ifdef MPD2_STAMPS
   // diagnostic build: wave 0 of each workgroup records (shader clock, 100 MHz real time)
   // at kernel start/end and the shader clock at 4 points of every step
-  unsigned long long* const dbgw = a.dbg ? a.dbg + (size_t)blockIdx.x * 256 : nullptr;
-  const bool stamp = dbgw && wave == 0 && blockIdx.y == 0;
+  unsigned long long* const dbgw = a.dbg ? a.dbg + (size_t)blockIdx.y * 256 : nullptr;
+  const bool stamp = dbgw && wave == 0 && blockIdx.x == 0;
   int stamp_i = 4;
   auto STAMP = [&]() __attribute__((always_inline)) {
     if (stamp && stamp_i < 256) {

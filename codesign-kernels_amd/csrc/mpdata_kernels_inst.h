@@ -38,8 +38,8 @@ static void launch_tile(const MpdataArgs& a, int ntracers, void* stream) {
 template <int LPS>
 static void launch_tile_v2(const MpdataArgs& a, int ntracers, void* stream) {
   using T = v2::TileV2<LPS>;
-  const unsigned gx = (unsigned)((a.ncrms + MPD2_G - 1) / MPD2_G);
-  dim3 grid(gx, (unsigned)ntracers, 1), block(T::THREADS, 1, 1);
+  const unsigned groups = (unsigned)((a.ncrms + MPD2_G - 1) / MPD2_G);
+  dim3 grid((unsigned)ntracers, groups, 1), block(T::THREADS, 1, 1);  // tracer fastest
   hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<LPS>), grid, block, 0, (hipStream_t)stream, a);
 }
 
