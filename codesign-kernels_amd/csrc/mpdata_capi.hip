@@ -94,7 +94,8 @@ int choose_tile(int var, int64_t ncrms, int nx, int nz, MpdataTileInfo* out) {
     if (t.ncol < nx + 4 || t.nz_max < nz) continue;
     if (t.nz_max < (1 << 30) && !small32) continue;
     // x-marching tiles (finite nz_max) first, by lanes per instance; then k-marching by columns
-    const int cost = t.nz_max < (1 << 30) ? t.nz_max : 100000 + t.ncol;
+    // (among x-marching tiles of equal lanes-per-instance the smaller workgroup is the default)
+    const int cost = t.nz_max < (1 << 30) ? t.nz_max * 100 + t.slw : 100000 + t.ncol;
     if (cost < best_cost) { best = id; best_cost = cost; }
   }
   if (best < 0)

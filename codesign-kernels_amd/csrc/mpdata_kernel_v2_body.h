@@ -58,9 +58,6 @@
 namespace MPDATA_NS {
 namespace v2 {
 
-#ifndef MPD2_G
-#define MPD2_G 16  // CRM instances per workgroup (128-byte rows)
-#endif
 #ifndef MPD2_AUX_LD
 #define MPD2_AUX_LD 0  // cache-policy bits of the DMA loads (2 = nt)
 #endif
@@ -181,15 +178,17 @@ __device__ __forceinline__ double shift_up_clamped(double x, bool top) {
   return top ? x : t;
 }
 
-template <int LPS>
+template <int LPS, int G_>
 struct TileV2 {
+  static constexpr int G = G_;                 // CRM instances per workgroup: rows of G*8 bytes
+  static constexpr int RPI = 32 / G_;          // rows moved by one DMA wave instruction (256 B)
   static constexpr int SLP = 64 / LPS;         // instances per wave
-  static constexpr int NWV = MPD2_G / SLP;     // waves per workgroup (= LPS/4)
+  static constexpr int NWV = G_ / SLP;         // waves per workgroup
   static constexpr int THREADS = 64 * NWV;     // = 16 * LPS
-  static constexpr int RS = MPD2_G + 1;        // out tile: LDS row stride in doubles
+  static constexpr int RS = G_ + 1;           // out tile: LDS row stride in doubles
   static constexpr int NZM_MAX = LPS - 1;
   static constexpr int NSLOT = 4;              // input ring: columns q .. q+3
-  static constexpr int ARR = LPS * MPD2_G;     // doubles of one array block (LPS rows x 16)
+  static constexpr int ARR = LPS * G_;         // doubles of one array block (LPS rows x G)
   static constexpr int IN_SLOT = 3 * ARR;      // f,u,w rows of one column
   static constexpr int OUT_SLOT = NZM_MAX * RS;
   static constexpr int LDS_DOUBLES = NSLOT * IN_SLOT + 2 * OUT_SLOT;
@@ -205,11 +204,12 @@ struct Window {
   double MXN[3], MNN[3], U3[3], DW3[3];             // written for column q-2
 };
 
-template <int LPS>
-__global__ void __launch_bounds__(MPD2_G * LPS, 4)
+template <int LPS, int G>
+__global__ void __launch_bounds__(G * LPS, 4)
 mpdata_advect_xmarch_kernel(const MpdataArgs a) {
-  using T = TileV2<LPS>;
-  constexpr int G = MPD2_G, RS = T::RS, SLP = T::SLP;
+  using T = TileV2<LPS, G>;
+  constexpr int RS = T::RS, SLP = T::SLP, RPI = T::RPI;
+  static_assert(G == 16 || G == 32, "row segments of 128 or 256 bytes");
   __shared__ double lds[T::LDS_DOUBLES];
   double* const in_slot0 = lds;
   double* const out_slot0 = lds + T::NSLOT * T::IN_SLOT;
@@ -285,20 +285,20 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   const __amdgpu_buffer_rsrc_t rsu = make_rsrc(a.u, ncrms * 8ll * (nx + 5) * nzm);
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.w, ncrms * 8ll * (nx + 4) * nz);
 
-  // ---- DMA mapping: one wave instruction moves two 128-byte rows (lanes 0-31:
-  //      row 2j, lanes 32-63: row 2j+1; 4 bytes per lane).  LDS image of a column:
+  // ---- DMA mapping: one wave instruction moves 256 bytes, 4 per lane = RPI rows
+  //      (G=16: two 128-byte rows, lanes 0-31 row 2j, lanes 32-63 row 2j+1; G=32: one row).  LDS image of a column:
   //      [array][row][16 doubles], double (row, sl) stored at position
-  //      sl ^ ((row>>1) & 15): the swizzle is applied to the SOURCE address.
-  const int np = (nzm + 1) >> 1;  // row pairs per array
-  unsigned vdf[2], vdu[2], vdw[2];  // per-lane source byte offsets of the wave's two pairs
+  //      sl ^ ((row / rows-per-instruction) & (G-1)): the swizzle is applied to the SOURCE address.
+  const int ni = (nzm + RPI - 1) / RPI;  // DMA instructions per array and column
+  unsigned vdf[2], vdu[2], vdw[2];  // per-lane source byte offsets of the wave's two instructions
   int jd[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const int j = min(wave + it * T::NWV, np - 1);  // (a clamped duplicate rewrites the same bytes)
+    const int j = min(wave + it * T::NWV, ni - 1);  // (a clamped duplicate rewrites the same bytes)
     jd[it] = j;
-    const int row = min(2 * j + (lane >> 5), nzm - 1);
-    const int p = (lane & 31) >> 1;
-    long long sl_d = sl_base + (p ^ (j & 15));
+    const int row = min(j * RPI + lane / (2 * G), nzm - 1);
+    const int p = (lane % (2 * G)) >> 1;
+    long long sl_d = sl_base + (p ^ (j & (G - 1)));
     if (sl_d >= ncrms) sl_d = ncrms - 1;
     const unsigned part = (lane & 1) * 4;
     vdf[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 6) * row) * 8) + part;
@@ -306,7 +306,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     vdw[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 4) * row) * 8) + part;
   }
   // compute-side read position inside one array block of a slot
-  const int c_lds = (kl - 1) * G + (sl_l ^ (((kl - 1) >> 1) & 15));
+  const int c_lds = (kl - 1) * G + (sl_l ^ (((kl - 1) / RPI) & (G - 1)));
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   // all DMA of column `col` into its ring slot (6 instructions per wave)
@@ -317,7 +317,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     double* slot = in_slot0 + (col & (T::NSLOT - 1)) * T::IN_SLOT;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      double* d = slot + jd[it] * 2 * G;
+      double* d = slot + jd[it] * 32;  // 256 bytes per instruction
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, MPD2_AUX_LD);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, MPD2_AUX_LD);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, MPD2_AUX_LD);

@@ -28,22 +28,24 @@ static void launch_tile(const MpdataArgs& a, int ntracers, void* stream) {
   X(9, 3, 2, 6)         \
   X(10, 3, 1, 12)
 
-// x-marching kernels (mpdata_kernel_v2_body.h): id, LPS (lanes per instance >= nz)
+// x-marching kernels (mpdata_kernel_v2_body.h): id, LPS (lanes per instance >= nz),
+// G (instances per workgroup: 128- or 256-byte row segments)
 #define MPDATA_TILES_V2(X) \
-  X(20, 8)                 \
-  X(21, 16)                \
-  X(22, 32)                \
-  X(23, 64)
+  X(20, 8, 16)             \
+  X(21, 16, 16)            \
+  X(22, 32, 16)            \
+  X(23, 64, 16)            \
+  X(24, 32, 32)
 
-template <int LPS>
+template <int LPS, int G>
 static void launch_tile_v2(const MpdataArgs& a, int ntracers, void* stream) {
-  using T = v2::TileV2<LPS>;
-  const unsigned groups = (unsigned)((a.ncrms + MPD2_G - 1) / MPD2_G);
+  using T = v2::TileV2<LPS, G>;
+  const unsigned groups = (unsigned)((a.ncrms + G - 1) / G);
   dim3 grid((unsigned)ntracers, groups, 1), block(T::THREADS, 1, 1);  // tracer fastest
-  hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<LPS>), grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<LPS, G>), grid, block, 0, (hipStream_t)stream, a);
 }
 
-int max_tile_id() { return 23; }
+int max_tile_id() { return 24; }
 
 bool tile_info(int id, MpdataTileInfo* info) {
 #define X(ID, W_, SPW_, NWV_)                                                     \
@@ -55,11 +57,11 @@ bool tile_info(int id, MpdataTileInfo* info) {
   }
   MPDATA_TILES(X)
 #undef X
-#define X(ID, LPS_)                                                                      \
+#define X(ID, LPS_, G_)                                                                  \
   if (id == ID) {                                                                        \
-    using T = v2::TileV2<LPS_>;                                                          \
-    *info = MpdataTileInfo{ID, 0, 0, T::NWV, MPD2_G, 1 << 30, LPS_, T::THREADS,          \
-                           "xmarch_LPS" #LPS_};                                          \
+    using T = v2::TileV2<LPS_, G_>;                                                      \
+    *info = MpdataTileInfo{ID, 0, 0, T::NWV, G_, 1 << 30, LPS_, T::THREADS,              \
+                           "xmarch_LPS" #LPS_ "_G" #G_};                                 \
     return true;                                                                         \
   }
   MPDATA_TILES_V2(X)
@@ -75,9 +77,9 @@ bool launch(int id, const MpdataArgs& a, int ntracers, void* stream) {
   }
   MPDATA_TILES(X)
 #undef X
-#define X(ID, LPS_)                               \
+#define X(ID, LPS_, G_)                           \
   if (id == ID) {                                 \
-    launch_tile_v2<LPS_>(a, ntracers, stream);    \
+    launch_tile_v2<LPS_, G_>(a, ntracers, stream); \
     return true;                                  \
   }
   MPDATA_TILES_V2(X)

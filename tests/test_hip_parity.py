@@ -23,7 +23,7 @@ TOL_ABS = 1e-12     # north_star tolerance, conditioned inputs
 TOL_RELL1 = 1e-14   # reference metric, raw inputs
 FLUX_RTOL = 1e-13   # x-marching kernels: summation order of flux differs
 KMARCH_TILES = [0, 1, 2, 3, 4]   # nx <= 32 (ids 3, 4: nx <= 68 / 140), any nz
-XMARCH_TILES = [22, 23]          # nz <= 32 / 64, any nx
+XMARCH_TILES = [22, 23, 24]      # nz <= 32 / 64 / 32 (256-byte rows), any nx
 
 
 def flux_close(flux, flux_ref):
