@@ -473,10 +473,27 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
         const double mx1 = dmax(dmax(dmax(dmax(dmax(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MX0[C2]);
         const double mn1 = dmin(dmin(dmin(dmin(dmin(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MN0[C2]);
         // :606-609
-        MXN_2 = ratio(RHO * (mx1 - S.F1[C2]),
-                      pn(U2_1) + pp(S.U2[C2]) + IADZ * (pn(W2u) + pp(W2_2)) + eps);
-        MNN_2 = ratio(RHO * (S.F1[C2] - mn1),
-                      pp(U2_1) + pn(S.U2[C2]) + IADZ * (pp(W2u) + pn(W2_2)) + eps);
+        const double num_mx = RHO * (mx1 - S.F1[C2]);
+        const double den_mx = pn(U2_1) + pp(S.U2[C2]) + IADZ * (pn(W2u) + pp(W2_2)) + eps;
+        const double num_mn = RHO * (S.F1[C2] - mn1);
+        const double den_mn = pp(U2_1) + pn(S.U2[C2]) + IADZ * (pp(W2u) + pn(W2_2)) + eps;
+#ifdef MPDATA_FAST_DIV
+        // FAST: one reciprocal for both ratios, r = 1/(den_mx*den_mn) (both >= eps = 1e-10,
+        // finite), two Newton steps, then a/b = a * (other denominator) * r
+        {
+          const double dd2 = den_mx * den_mn;
+          double r = __builtin_amdgcn_rcp(dd2);
+          double e = __builtin_fma(-dd2, r, 1.0);
+          r = __builtin_fma(r, e, r);
+          e = __builtin_fma(-dd2, r, 1.0);
+          r = __builtin_fma(r, e, r);
+          MXN_2 = num_mx * (den_mn * r);
+          MNN_2 = num_mn * (den_mx * r);
+        }
+#else
+        MXN_2 = num_mx / den_mx;
+        MNN_2 = num_mn / den_mn;
+#endif
       }
     }
     S.U2[C1] = U2_1;

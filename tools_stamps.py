@@ -25,13 +25,22 @@ dur = (r1 - r0) / 100e6 * 1e6
 print("blocks", nblk, "per-WG lifetime us: median %.1f min %.1f max %.1f" % (np.median(dur), dur.min(), dur.max()))
 print("shader clock GHz: median %.3f min %.3f max %.3f" % (np.median(clk), clk.min(), clk.max()))
 print("kernel span us (first start to last end): %.1f" % ((r1.max() - r0.min()) / 100e6 * 1e6))
-st = s[:, 4:4 + 5 * 42].reshape(nblk, 42, 5).astype(np.float64)
-# per step: [before wait, after wait, after barrier, before stage B, (next step's first)]
+NS = 42
+st = s[:, 4:4 + 4 * NS].reshape(nblk, NS, 4).astype(np.float64)
+# per step: [before wait, after wait, after barrier, before stage B]
 w = st[:, :, 1] - st[:, :, 0]
 b = st[:, :, 2] - st[:, :, 1]
 a = st[:, :, 3] - st[:, :, 2]
-rest = np.concatenate([st[:, 1:, 0], st[:, -1:, 3]], axis=1) - st[:, :, 3]
-tot = np.concatenate([st[:, 1:, 0] - st[:, :-1, 0]], axis=1)
+rest = st[:, 1:, 0] - st[:, :-1, 3]
+tot = st[:, 1:, 0] - st[:, :-1, 0]
 for name, x in (("vmcnt/lgkm wait", w), ("barrier", b), ("DMA+read+stage A", a), ("stage B..D", rest)):
     print("%-18s median per step %7.0f cyc   (steps 10..30: %7.0f)" % (name, np.median(x), np.median(x[:, 10:30])))
 print("step total (steady) median %.0f cycles" % np.median(tot[:, 10:30]))
+print("median step duration by step index (cycles):")
+print(" ".join("%d" % x for x in np.median(tot, axis=0)))
+print("vmcnt wait by step:", " ".join("%d" % x for x in np.median(w, axis=0)))
+print("barrier by step:   ", " ".join("%d" % x for x in np.median(b, axis=0)))
+print("stage A by step:   ", " ".join("%d" % x for x in np.median(a, axis=0)))
+print("stage B-D by step: ", " ".join("%d" % x for x in np.median(rest, axis=0)))
+r0s = (s[:, 1] - s[:, 1].min()) / 100.0
+print("WG start times us: p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(r0s, [10, 50, 90, 100])))
