@@ -64,6 +64,12 @@ namespace v2 {
 #ifndef MPD2_AUX_ST
 #define MPD2_AUX_ST 0  // ... of the row stores
 #endif
+#ifndef MPD2_DIRECT_ST
+#define MPD2_DIRECT_ST 0  // 1 (experiment, per-step barrier): direct untransposed stores instead of the out tile
+#endif
+#ifndef MPD2_TRIPLE
+#define MPD2_TRIPLE 0  // 1: one barrier per three columns, 6-column LDS ring, direct (untransposed) stores
+#endif
 #ifndef MPD2_XCD_REMAP
 #define MPD2_XCD_REMAP 0
 #endif
@@ -187,11 +193,19 @@ struct TileV2 {
   static constexpr int THREADS = 64 * NWV;     // = 16 * LPS
   static constexpr int RS = G_ + 1;           // out tile: LDS row stride in doubles
   static constexpr int NZM_MAX = LPS - 1;
+#if MPD2_TRIPLE
+  static constexpr int NSLOT = 6;              // input ring: the triple being computed + the next one
+#else
   static constexpr int NSLOT = 4;              // input ring: columns q .. q+3
+#endif
   static constexpr int ARR = LPS * G_;         // doubles of one array block (LPS rows x G)
   static constexpr int IN_SLOT = 3 * ARR;      // f,u,w rows of one column
   static constexpr int OUT_SLOT = NZM_MAX * RS;
+#if MPD2_TRIPLE
+  static constexpr int LDS_DOUBLES = NSLOT * IN_SLOT;
+#else
   static constexpr int LDS_DOUBLES = NSLOT * IN_SLOT + 2 * OUT_SLOT;
+#endif
   static constexpr int VM_PER_STEP = 7;        // 1 store + 6 DMA per wave and step
 };
 
@@ -308,13 +322,20 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   // compute-side read position inside one array block of a slot
   const int c_lds = (kl - 1) * G + (sl_l ^ (((kl - 1) / RPI) & (G - 1)));
 
+  // direct (untransposed) store of a finished column: lane (instance, level) writes its own 8 bytes
+  const unsigned vst = (lvl_ok && slc_ok) ? (unsigned)((sl_c + ncrms * (long long)(nx + 6) * (k - 1)) * 8) : OOB;
+
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   // all DMA of column `col` into its ring slot (6 instructions per wave)
   auto dma_col = [&](const int col) __attribute__((always_inline)) {
     const unsigned cf = colb * (unsigned)(min(max(col, -2), nx + 3) + 2);
     const unsigned cu = colb * (unsigned)(min(max(col, -1), nx + 3) + 1);
     const unsigned cw = colb * (unsigned)(min(max(col, -1), nx + 2) + 1);
+#if MPD2_TRIPLE
+    double* slot = in_slot0 + ((col + 2) % 6) * T::IN_SLOT;
+#else
     double* slot = in_slot0 + (col & (T::NSLOT - 1)) * T::IN_SLOT;
+#endif
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       double* d = slot + jd[it] * 32;  // 256 bytes per instruction
@@ -363,6 +384,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr int C0 = PH, C1 = (PH + 2) % 3, C2 = (PH + 1) % 3, C3 = PH;  // slots of q, q-1, q-2, q-3
 
+#if !MPD2_TRIPLE
     // column q landed (this wave's DMA of it is 2 steps = 14 vector-memory ops
     // old), out tile of column q-4 written: then everyone's are, after the barrier
     STAMP();
@@ -374,20 +396,23 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 
     // ---- write back the column finished in the previous step (n = q-4); an
     //      inactive step stores out of range (dropped), the op count stays fixed
+#if !MPD2_DIRECT_ST
     {
       const bool act = q - 4 >= -1 && q - 4 <= nx + 2;
-#ifdef MPD2_ABL_NOSTORE
-      st_row(rsf, OOB, colb * (unsigned)max(q - 4 + 2, 0),
-#else
       st_row(rsf, (FULL || act) ? tf : OOB, colb * (unsigned)max(q - 4 + 2, 0),
-#endif
              out_slot0[((q - 1) & 1) * T::OUT_SLOT + t_lds]);
     }
+#endif
     // ---- column q+3 into flight -------------------------------------------------
     dma_col(q + 3);
+#endif
 
     // ---- this column, transposed: lanes along k -------------------------------
+#if MPD2_TRIPLE
+    const double* s = in_slot0 + ((q + 2) % 6) * T::IN_SLOT;
+#else
     const double* s = in_slot0 + (q & (T::NSLOT - 1)) * T::IN_SLOT;
+#endif
     const double f0q = s[c_lds];
     const double uq = s[T::ARR + c_lds];
     const double wq = lvl_ok ? s[2 * T::ARR + c_lds] : 0.0;  // ghost level: w = 0
@@ -520,8 +545,15 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
         double v = S.F1[C3];  // halo columns keep the first-pass value (:557)
         if (FULL || (n >= 1 && n <= nx))
           v = dmax(0.0, S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
+#if MPD2_TRIPLE || MPD2_DIRECT_ST
+        st_row(rsf, vst, colb * (unsigned)(n + 2), v);
+#else
         if (lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = v;
+#endif
       }
+#if MPD2_TRIPLE || MPD2_DIRECT_ST
+      else st_row(rsf, OOB, 0, 0.0);  // keep the vector-memory op count per step fixed
+#endif
     }
     S.U3[C2] = U3_2;
     S.DW3[C2] = DW3_2;
@@ -535,6 +567,27 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   using Part = std::false_type;
 
   const int q_first = -2;
+#if MPD2_TRIPLE
+  // One synchronisation per three columns.  At the top of a triple: this wave's DMA of
+  // the triple's columns (issued at the top of the previous triple, followed by the three
+  // stores of that triple) has landed, everyone's has after the barrier, and all waves have
+  // left the previous triple, whose ring slots the next triple's DMA may overwrite.
+  auto triple_sync = [&](const int q0) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    dma_col(q0 + 3);
+    dma_col(q0 + 4);
+    dma_col(q0 + 5);
+  };
+  dma_col(q_first);
+  dma_col(q_first + 1);
+  dma_col(q_first + 2);
+  st_row(rsf, OOB, 0, 0.0);
+  st_row(rsf, OOB, 0, 0.0);
+  st_row(rsf, OOB, 0, 0.0);
+#define MPD_TRIPLE_SYNC(q0) triple_sync(q0)
+#else
   // columns -2, -1, 0 into flight, each behind a dropped store so that the
   // counted wait of the first steps sees the steady-state op pattern
 #pragma unroll
@@ -542,6 +595,8 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     st_row(rsf, OOB, 0, 0.0);
     dma_col(c);
   }
+#define MPD_TRIPLE_SYNC(q0) ((void)0)
+#endif
 
   // q advances by 3 per trip so that the ring phase is a compile-time constant.
   // Steps always run in whole triples (no step is skipped, so no ring slot stays
@@ -550,18 +605,21 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   {
     int q = q_first;
     for (; q < 4; q += 3) {  // columns -2 .. 3: pipeline fill
+      MPD_TRIPLE_SYNC(q);
       step(P0{}, Part{}, q);
       step(P1{}, Part{}, q + 1);
       step(P2{}, Part{}, q + 2);
     }
 #if MPD2_USE_FULL
     for (; q + 2 <= nx; q += 3) {  // steady state: every stage active, no conditions
+      MPD_TRIPLE_SYNC(q);
       step(P0{}, Full{}, q);
       step(P1{}, Full{}, q + 1);
       step(P2{}, Full{}, q + 2);
     }
 #endif
     for (; q <= nx + 6; q += 3) {  // remaining columns and pipeline drain
+      MPD_TRIPLE_SYNC(q);
       step(P0{}, Part{}, q);
       step(P1{}, Part{}, q + 1);
       step(P2{}, Part{}, q + 2);
