@@ -89,6 +89,11 @@ __device__ __forceinline__ double andiff(double x1, double x2, double a, double 
 __device__ __forceinline__ double across(double x1, double a1, double a2) {
   return 0.03125 * a1 * a2 * x1;
 }
+// max(0,a)*x + min(0,a)*y of the reference's upwind / limited fluxes (:532, :537, :618, :623).
+// One of the two products is an exact zero, so the value equals a * (a >= 0 ? x : y)
+// (the sign of a zero result aside); one select + one multiply instead of max, min, two
+// multiplies and an add.
+__device__ __forceinline__ double upwind(double a, double x, double y) { return a * (a >= 0.0 ? x : y); }
 __device__ __forceinline__ double pp(double y) { return dmax(0.0, y); }
 __device__ __forceinline__ double pn(double y) { return -dmin(0.0, y); }
 
@@ -421,7 +426,12 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     if (q - 3 >= -1 && q - 3 <= nx + 2 && lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = f0q + uq + wq;
     return;
 #endif
-#if MPD2_DPP
+#if MPD2_DPP == 2  // mixed: clamped up-shifts through the LDS crossbar (no VALU slot), the rest by DPP
+#define DN_C(x) shift_dn_clamped<LPS>((x), k_is_1)
+#define DN_P(x) shift_dn(x)
+#define UP_C(x) lane_get(a_upc, (x))
+#define UP_G(x) shift_up(x)
+#elif MPD2_DPP
 #define DN_C(x) shift_dn_clamped<LPS>((x), k_is_1)
 #define DN_P(x) shift_dn(x)
 #define UP_C(x) shift_up_clamped((x), k_ge_nzm)
@@ -433,7 +443,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 #define UP_G(x) lane_get(a_upg, (x))
 #endif
     const double f0d = DN_C(f0q);
-    const double f0u = UP_C(f0q);
+    const double f0u = UP_G(f0q);  // lanes above nzm load level nzm: the plain shift IS the kc clamp
     const double F0p = S.F0[C1];
 
     // ================= stage A =================================================
@@ -441,9 +451,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     //  q-3 is dead afterwards: inactive stages store zeros)
     double U1q = 0.0, DW1q = 0.0, f1_1 = 0.0, F1D_1 = 0.0, F1U_1 = 0.0, MX0_1 = 0.0, MN0_1 = 0.0;
     if (FULL || (q >= -1 && q <= nx + 3)) {
-      U1q = dmax(0.0, uq) * F0p + dmin(0.0, uq) * f0q;  // :532
+      U1q = upwind(uq, F0p, f0q);  // :532
       if (FULL || q <= nx + 2) {
-        const double W1q = dmax(0.0, wq) * f0d + dmin(0.0, wq) * f0q;  // :537
+        const double W1q = upwind(wq, f0d, f0q);  // :537
         DW1q = UP_G(W1q) - W1q;
         if (FULL || (q >= 1 && q <= nx)) S1 = S1 + W1q;  // :545
       }
@@ -528,13 +538,12 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     // ================= stage D =================================================
     double U3_2 = 0.0, DW3_2 = 0.0;
     if (FULL || (q >= 3 && q <= nx + 3)) {
-      U3_2 = pp(S.U2[C2]) * dmin(dmin(1.0, MXN_2), S.MNN[C3]) -
-             pn(S.U2[C2]) * dmin(dmin(1.0, S.MXN[C3]), MNN_2);  // :618
+      U3_2 = upwind(S.U2[C2], dmin(dmin(1.0, MXN_2), S.MNN[C3]),
+                    dmin(dmin(1.0, S.MXN[C3]), MNN_2));  // :618  pp(u)*m1 - pn(u)*m2
       if (FULL || q <= nx + 2) {
         const double mxd = DN_C(MXN_2);
         const double mnd = DN_C(MNN_2);
-        const double W3 = pp(W2_2) * dmin(dmin(1.0, MXN_2), mnd) -
-                          pn(W2_2) * dmin(dmin(1.0, mxd), MNN_2);  // :623
+        const double W3 = upwind(W2_2, dmin(dmin(1.0, MXN_2), mnd), dmin(dmin(1.0, mxd), MNN_2));  // :623
         S3 = S3 + W3;  // :624
         DW3_2 = UP_G(W3) - W3;
       }
