@@ -569,6 +569,11 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 
   };
 
+#undef DN_C
+#undef DN_P
+#undef UP_C
+#undef UP_G
+
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   using P2 = std::integral_constant<int, 2>;

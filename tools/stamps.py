@@ -2,7 +2,7 @@
 import os, sys, ctypes
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import codesign_kernels_amd as M
 ncrms, nx, nz = 65536, 32, 28
 M.set_variant(M.VARIANT_FAST if (len(sys.argv) > 1 and sys.argv[1] == "fast") else M.VARIANT_EXACT)
