@@ -153,37 +153,30 @@ __device__ __forceinline__ double lane_get(int addr, double v) {
 // LDS-crossbar permutes (ds_bpermute) cost no VALU slot but ~5 LDS cycles per
 // CU each and, measured with in-kernel clock stamps, enough power that the chip
 // drops its clock by ~15 %; DPP moves are two 32-bit VALU passes per double.
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ double dpp_mov(double old, double src) {
-  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, BANK_MASK, false);
-  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, BANK_MASK, false);
+// A lane without a source lane reads 0 (bound_ctrl), so the move needs no prior copy of
+// its destination (with bound_ctrl off the destination is an input -- "keep the old
+// value" -- and hipcc spends a v_mov per half to set it up).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double src) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, 0xF, 0xF, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-#define MPD_DPP_ROW_SHR1 0x111
 #define MPD_DPP_WAVE_SHL1 0x130
 #define MPD_DPP_WAVE_SHR1 0x138
 
-// value of lane-1 (level kb); lanes with no source keep their own value
+// value of lane-1 (level k-1); lane 0 reads 0
+__device__ __forceinline__ double shift_dn(double x) { return dpp_mov<MPD_DPP_WAVE_SHR1>(x); }
+// value of lane+1 (level k+1); lane 63 reads 0
+__device__ __forceinline__ double shift_up(double x) { return dpp_mov<MPD_DPP_WAVE_SHL1>(x); }
+// ... with the clamps kb = max(1,k-1) / kc = min(nzm,k+1).  The move is executed by ALL
+// lanes before the select: under a divergent EXEC mask a DPP source lane that is switched
+// off counts as missing.
 template <int LPS>
 __device__ __forceinline__ double shift_dn_clamped(double x, bool k_is_1) {
-  if constexpr (LPS == 64) {
-    return dpp_mov<MPD_DPP_WAVE_SHR1, 0xF, 0xF>(x, x);            // lane 0 keeps x: kb clamp at k = 1
-  } else if constexpr (LPS == 16) {
-    return dpp_mov<MPD_DPP_ROW_SHR1, 0xF, 0xF>(x, x);             // every 16-lane row starts an instance
-  } else if constexpr (LPS == 32) {
-    double r = dpp_mov<MPD_DPP_ROW_SHR1, 0xF, 0xF>(x, x);         // lanes 0,16,32,48 keep x
-    return dpp_mov<MPD_DPP_WAVE_SHR1, 0xA, 0x1>(r, x);            // lanes 16-19, 48-51 <- lane-1
-  } else {
-    double r = dpp_mov<MPD_DPP_WAVE_SHR1, 0xF, 0xF>(x, x);
-    return k_is_1 ? x : r;
-  }
+  const double t = shift_dn(x);
+  return k_is_1 ? x : t;
 }
-__device__ __forceinline__ double shift_dn(double x) { return dpp_mov<MPD_DPP_WAVE_SHR1, 0xF, 0xF>(x, x); }
-// value of lane+1 (level k+1); the last lane keeps its own value
-__device__ __forceinline__ double shift_up(double x) { return dpp_mov<MPD_DPP_WAVE_SHL1, 0xF, 0xF>(x, x); }
-// ... clamped at the top level (kc = min(nzm,k+1)).  The move is executed by ALL lanes
-// before the select: under a divergent EXEC mask a DPP source lane that is switched off
-// counts as missing and the reader silently keeps its own value.
 __device__ __forceinline__ double shift_up_clamped(double x, bool top) {
   const double t = shift_up(x);
   return top ? x : t;
