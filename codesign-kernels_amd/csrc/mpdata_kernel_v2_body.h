@@ -212,7 +212,7 @@ struct Window {
   double F0[3], PMX[3], PMN[3], U1[3], DW1[3];      // written for column q
   double F1[3], F1D[3], F1U[3], MX0[3], MN0[3];     // written for column q-1
   double UR[3], UD[3], PW[3], SW[3], WR[3];         // u, u(kb), w+w(kc), w-sum, w of column q
-  double SU[3], U2[3];                              // written for column q-1
+  double SU[3], U2P[3], U2N[3];                     // written for column q-1 (pp / pn of U2)
   double MXN[3], MNN[3], U3[3], DW3[3];             // written for column q-2
 };
 
@@ -370,7 +370,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   for (int j = 0; j < 3; ++j) {
     S.F0[j] = S.PMX[j] = S.PMN[j] = S.U1[j] = S.DW1[j] = 0.0;
     S.F1[j] = S.F1D[j] = S.F1U[j] = S.MX0[j] = S.MN0[j] = 0.0;
-    S.UR[j] = S.UD[j] = S.PW[j] = S.SW[j] = S.WR[j] = S.SU[j] = S.U2[j] = 0.0;
+    S.UR[j] = S.UD[j] = S.PW[j] = S.SW[j] = S.WR[j] = S.SU[j] = S.U2P[j] = S.U2N[j] = 0.0;
     S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = 0.0;
   }
   double S1 = 0, S3 = 0;
@@ -419,7 +419,12 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     if (q - 3 >= -1 && q - 3 <= nx + 2 && lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = f0q + uq + wq;
     return;
 #endif
-#if MPD2_DPP == 2  // mixed: clamped up-shifts through the LDS crossbar (no VALU slot), the rest by DPP
+#if MPD2_DPP == 3  // mixed: every clamped shift through the LDS crossbar, the plain ones by DPP
+#define DN_C(x) lane_get(a_dn, (x))
+#define DN_P(x) shift_dn(x)
+#define UP_C(x) lane_get(a_upc, (x))
+#define UP_G(x) shift_up(x)
+#elif MPD2_DPP == 2  // mixed: clamped up-shifts through the LDS crossbar (no VALU slot), the rest by DPP
 #define DN_C(x) shift_dn_clamped<LPS>((x), k_is_1)
 #define DN_P(x) shift_dn(x)
 #define UP_C(x) lane_get(a_upc, (x))
@@ -482,12 +487,14 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 
     STAMP();
     // ================= stage B/C ===============================================
-    double U2_1 = 0.0, W2_2 = 0.0, MXN_2 = 0.0, MNN_2 = 0.0;
+    double U2_1 = 0.0, U2p_1 = 0.0, U2n_1 = 0.0, W2_2 = 0.0, W2p = 0.0, W2n = 0.0, MXN_2 = 0.0, MNN_2 = 0.0;
     if (FULL || (q >= 1 && q <= nx + 3)) {
       {  // :571-573, column q-1
         const double ad = andiff(S.F1[C2], f1_1, S.UR[C1], IRHO);
         const double x = __builtin_ldexp(IADZ * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1), dd_exp);
         U2_1 = ad - across(x, S.UR[C1], S.SW[C1]) * IRHO;
+        U2p_1 = pp(U2_1);
+        U2n_1 = pn(U2_1);
       }
       if (FULL || q >= 2) {  // column q-2
         {  // :580-582, :586
@@ -501,10 +508,12 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
         const double mx1 = dmax(dmax(dmax(dmax(dmax(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MX0[C2]);
         const double mn1 = dmin(dmin(dmin(dmin(dmin(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MN0[C2]);
         // :606-609
+        W2p = pp(W2_2);
+        W2n = pn(W2_2);
         const double num_mx = RHO * (mx1 - S.F1[C2]);
-        const double den_mx = pn(U2_1) + pp(S.U2[C2]) + IADZ * (pn(W2u) + pp(W2_2)) + eps;
+        const double den_mx = U2n_1 + S.U2P[C2] + IADZ * (pn(W2u) + W2p) + eps;
         const double num_mn = RHO * (S.F1[C2] - mn1);
-        const double den_mn = pp(U2_1) + pn(S.U2[C2]) + IADZ * (pp(W2u) + pn(W2_2)) + eps;
+        const double den_mn = U2p_1 + S.U2N[C2] + IADZ * (pp(W2u) + W2n) + eps;
 #ifdef MPDATA_FAST_DIV
         // FAST: one reciprocal for both ratios, r = 1/(den_mx*den_mn) (both >= eps = 1e-10,
         // finite), two Newton steps, then a/b = a * (other denominator) * r.
@@ -529,18 +538,19 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
         MNN_2 = dmin(1.0, MNN_2);
       }
     }
-    S.U2[C1] = U2_1;
+    S.U2P[C1] = U2p_1;
+    S.U2N[C1] = U2n_1;
     S.MXN[C2] = MXN_2;
     S.MNN[C2] = MNN_2;
 
     // ================= stage D =================================================
     double U3_2 = 0.0, DW3_2 = 0.0;
     if (FULL || (q >= 3 && q <= nx + 3)) {
-      U3_2 = upwind(S.U2[C2], dmin(MXN_2, S.MNN[C3]), dmin(S.MXN[C3], MNN_2));  // :618  pp(u)*m1 - pn(u)*m2
+      U3_2 = S.U2P[C2] * dmin(MXN_2, S.MNN[C3]) - S.U2N[C2] * dmin(S.MXN[C3], MNN_2);  // :618
       if (FULL || q <= nx + 2) {
         const double mxd = DN_C(MXN_2);
         const double mnd = DN_C(MNN_2);
-        const double W3 = upwind(W2_2, dmin(MXN_2, mnd), dmin(mxd, MNN_2));  // :623
+        const double W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
         S3 = S3 + W3;  // :624
         DW3_2 = UP_G(W3) - W3;
       }
