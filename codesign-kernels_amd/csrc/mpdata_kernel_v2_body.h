@@ -274,6 +274,10 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   // :569  dd = 2./(kc-kb)/adz = (2 or 1)*(1/adz) exactly; the factor 2 is applied as an
   // exponent step on dd*(...) (exact scaling, bit-identical)
   const int dd_exp = (k == 1 || k == nzm) ? 1 : 0;
+#ifdef MPDATA_FAST_DIV
+  const double KW = 0.03125 * IRHO;
+  const double KU = __builtin_ldexp(KW * IADZ, dd_exp);
+#endif
   const bool k_is_1 = k == 1;
   const bool k_ge_nzm = k >= nzm;
 
@@ -490,17 +494,33 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     double U2_1 = 0.0, U2p_1 = 0.0, U2n_1 = 0.0, W2_2 = 0.0, W2p = 0.0, W2n = 0.0, MXN_2 = 0.0, MNN_2 = 0.0;
     if (FULL || (q >= 1 && q <= nx + 3)) {
       {  // :571-573, column q-1
+#ifdef MPDATA_FAST_DIV
+        // FAST: the constant factors 0.03125 * irho * dd of the cross term are one per-lane
+        // constant (same real-arithmetic value, 3 operations fewer)
+        const double u1 = S.UR[C1];
+        const double t1 = __builtin_fabs(u1) - (u1 * u1) * IRHO;
+        const double x4 = S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1;
+        U2_1 = 0.5 * (t1 * (f1_1 - S.F1[C2])) - KU * ((u1 * S.SW[C1]) * x4);
+#else
         const double ad = andiff(S.F1[C2], f1_1, S.UR[C1], IRHO);
         const double x = __builtin_ldexp(IADZ * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1), dd_exp);
         U2_1 = ad - across(x, S.UR[C1], S.SW[C1]) * IRHO;
+#endif
         U2p_1 = pp(U2_1);
         U2n_1 = pn(U2_1);
       }
       if (FULL || q >= 2) {  // column q-2
         {  // :580-582, :586
+#ifdef MPDATA_FAST_DIV
+          const double w2 = S.WR[C2];
+          const double t1 = __builtin_fabs(w2) - (w2 * w2) * IRHOW;
+          const double x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
+          const double v = 0.5 * (t1 * (S.F1[C2] - S.F1D[C2])) - KW * ((w2 * S.SU[C2]) * x4);
+#else
           const double ad = andiff(S.F1D[C2], S.F1[C2], S.WR[C2], IRHOW);
           const double x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
           const double v = ad - across(x, S.WR[C2], S.SU[C2]) * IRHO;
+#endif
           W2_2 = k_is_1 ? 0.0 : v;
         }
         const double W2u = UP_C(W2_2);
