@@ -659,12 +659,58 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
       step(P2{}, Full{}, q + 2);
     }
 #endif
+#if MPD2_TRIPLE
     for (; q <= nx + 6; q += 3) {  // remaining columns and pipeline drain
       MPD_TRIPLE_SYNC(q);
       step(P0{}, Part{}, q);
       step(P1{}, Part{}, q + 1);
       step(P2{}, Part{}, q + 2);
     }
+#else
+    // Remaining columns up to q = nx+3, the last step that computes anything (final field
+    // of column nx, first-pass values of nx+1 and nx+2).  What is left after it -- three
+    // columns to write back -- is done at once by the epilogue instead of by three more
+    // (almost empty) steps with their barriers.
+    for (; q + 2 <= nx + 3; q += 3) {
+      step(P0{}, Part{}, q);
+      step(P1{}, Part{}, q + 1);
+      step(P2{}, Part{}, q + 2);
+    }
+    auto epilogue = [&](auto ph_tag) __attribute__((always_inline)) {
+      constexpr int PH = decltype(ph_tag)::value;            // ring phase of the last step qe = nx+3
+      constexpr int C1 = (PH + 2) % 3, C2 = (PH + 1) % 3;    // slots of columns nx+2, nx+1
+      const int qe = nx + 3;
+      // every wave has finished step qe (its out tile holds column nx), nothing is in
+      // flight into the input ring any more: its first slot serves as a third tile
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      double* const tA = out_slot0 + (qe & 1) * T::OUT_SLOT;
+      double* const tB = out_slot0 + ((qe & 1) ^ 1) * T::OUT_SLOT;
+      double* const tC = in_slot0;
+      if (lvl_ok) {
+        tB[(k - 1) * RS + sl_l] = S.F1[C2];  // halo columns keep the first-pass value (:557)
+        tC[(k - 1) * RS + sl_l] = S.F1[C1];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      st_row(rsf, tf, colb * (unsigned)(nx + 2), tA[t_lds]);
+      st_row(rsf, tf, colb * (unsigned)(nx + 3), tB[t_lds]);
+      st_row(rsf, tf, colb * (unsigned)(nx + 4), tC[t_lds]);
+    };
+    const int rem = nx + 4 - q;  // 0, 1 or 2 single steps left
+    if (rem == 0) {
+      epilogue(P2{});
+    } else if (rem == 1) {
+      step(P0{}, Part{}, q);
+      epilogue(P0{});
+    } else {
+      step(P0{}, Part{}, q);
+      step(P1{}, Part{}, q + 1);
+      epilogue(P1{});
+    }
+#endif
   }
 
 #ifdef MPD2_STAMPS

@@ -25,7 +25,7 @@ dur = (r1 - r0) / 100e6 * 1e6
 print("blocks", nblk, "per-WG lifetime us: median %.1f min %.1f max %.1f" % (np.median(dur), dur.min(), dur.max()))
 print("shader clock GHz: median %.3f min %.3f max %.3f" % (np.median(clk), clk.min(), clk.max()))
 print("kernel span us (first start to last end): %.1f" % ((r1.max() - r0.min()) / 100e6 * 1e6))
-NS = 42
+NS = nx + 6  # column steps q = -2 .. nx+3
 st = s[:, 4:4 + 4 * NS].reshape(nblk, NS, 4).astype(np.float64)
 # per step: [before wait, after wait, after barrier, before stage B]
 w = st[:, :, 1] - st[:, :, 0]
