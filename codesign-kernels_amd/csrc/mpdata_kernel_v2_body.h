@@ -197,7 +197,7 @@ struct TileV2 {
   static constexpr int NSLOT = 4;              // input ring: columns q .. q+3
 #endif
   static constexpr int ARR = LPS * G_;         // doubles of one array block (LPS rows x G)
-  static constexpr int IN_SLOT = 3 * ARR;      // f,u,w rows of one column
+  static constexpr int IN_SLOT = 3 * ARR + G_; // f,u,w rows of one column + one row of zeros
   static constexpr int OUT_SLOT = NZM_MAX * RS;
 #if MPD2_TRIPLE
   static constexpr int LDS_DOUBLES = NSLOT * IN_SLOT;
@@ -277,6 +277,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 #ifdef MPDATA_FAST_DIV
   const double KW = 0.03125 * IRHO;
   const double KU = __builtin_ldexp(KW * IADZ, dd_exp);
+  const double HALFW = (k == 1) ? 0.0 : 0.5, KWW = (k == 1) ? 0.0 : KW;
 #endif
   const bool k_is_1 = k == 1;
   const bool k_ge_nzm = k >= nzm;
@@ -323,6 +324,8 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   }
   // compute-side read position inside one array block of a slot
   const int c_lds = (kl - 1) * G + (sl_l ^ (((kl - 1) / RPI) & (G - 1)));
+  // w of the lanes above nzm (ghost level nz and dead lanes) is 0: they read the zero row of the slot
+  const int c_lds_w = lvl_ok ? 2 * T::ARR + c_lds : 3 * T::ARR + sl_l;
 
   // direct (untransposed) store of a finished column: lane (instance, level) writes its own 8 bytes
   const unsigned vst = (lvl_ok && slc_ok) ? (unsigned)((sl_c + ncrms * (long long)(nx + 6) * (k - 1)) * 8) : OOB;
@@ -417,7 +420,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 #endif
     const double f0q = s[c_lds];
     const double uq = s[T::ARR + c_lds];
-    const double wq = lvl_ok ? s[2 * T::ARR + c_lds] : 0.0;  // ghost level: w = 0
+    const double wq = s[c_lds_w];  // ghost level: w = 0 (zero row)
 
 #ifdef MPD2_ABL_NOCOMPUTE  // timing ablation only: data movement without the arithmetic
     if (q - 3 >= -1 && q - 3 <= nx + 2 && lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = f0q + uq + wq;
@@ -515,13 +518,14 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
           const double w2 = S.WR[C2];
           const double t1 = __builtin_fabs(w2) - (w2 * w2) * IRHOW;
           const double x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
-          const double v = 0.5 * (t1 * (S.F1[C2] - S.F1D[C2])) - KW * ((w2 * S.SU[C2]) * x4);
+          // (HALFW and KWW are 0 in the lanes of level 1: www(:,:,:,1) = 0, :586)
+          W2_2 = HALFW * (t1 * (S.F1[C2] - S.F1D[C2])) - KWW * ((w2 * S.SU[C2]) * x4);
 #else
           const double ad = andiff(S.F1D[C2], S.F1[C2], S.WR[C2], IRHOW);
           const double x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
           const double v = ad - across(x, S.WR[C2], S.SU[C2]) * IRHO;
-#endif
           W2_2 = k_is_1 ? 0.0 : v;
+#endif
         }
         const double W2u = UP_C(W2_2);
         // :596-597
@@ -608,6 +612,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   using Part = std::false_type;
 
   const int q_first = -2;
+  // the zero row of every ring slot (never touched by the DMA)
+  if (tid < T::NSLOT * G) in_slot0[(tid / G) * T::IN_SLOT + 3 * T::ARR + (tid % G)] = 0.0;
+
 #if MPD2_TRIPLE
   // One synchronisation per three columns.  At the top of a triple: this wave's DMA of
   // the triple's columns (issued at the top of the previous triple, followed by the three
