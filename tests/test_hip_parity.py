@@ -112,6 +112,18 @@ def test_ragged_and_edge_shapes(M, oracle, shape, variant):
 
 
 @pytest.mark.parametrize("variant", [0, 1], ids=["exact", "fast"])
+def test_many_small_shapes(M, oracle, variant):
+    """Every nx mod 3 (pipeline tail variants), nz around the lane-group sizes, odd ncrms."""
+    rng = np.random.default_rng(1234)
+    M.set_tile(-1)
+    shapes = [(int(rng.integers(1, 70)), nx, int(rng.integers(3, 20))) for nx in range(1, 19)]
+    shapes += [(int(rng.integers(1, 40)), int(rng.integers(1, 40)), nz) for nz in (3, 7, 8, 9, 15, 16, 17, 31, 32)]
+    for shape in shapes:
+        inp = oracle.make_inputs(*shape, seed=int(rng.integers(1, 10**6)), dist=oracle.DIST_CONDITIONED)
+        check(M, oracle, inp, variant, oracle.DIST_CONDITIONED)
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["exact", "fast"])
 def test_reference_raw_distribution(M, oracle, variant):
     """The reference's own input law (everything U[0,1), reference :654-660)."""
     inp = oracle.make_inputs(256, 32, 28, seed=100, dist=oracle.DIST_RAW)
