@@ -277,7 +277,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 #ifdef MPDATA_FAST_DIV
   const double KW = 0.03125 * IRHO;
   const double KU = __builtin_ldexp(KW * IADZ, dd_exp);
-  const double HALFW = (k == 1) ? 0.0 : 0.5, KWW = (k == 1) ? 0.0 : KW;
 #endif
   const bool k_is_1 = k == 1;
   const bool k_ge_nzm = k >= nzm;
@@ -518,14 +517,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
           const double w2 = S.WR[C2];
           const double t1 = __builtin_fabs(w2) - (w2 * w2) * IRHOW;
           const double x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
-          // (HALFW and KWW are 0 in the lanes of level 1: www(:,:,:,1) = 0, :586)
-          W2_2 = HALFW * (t1 * (S.F1[C2] - S.F1D[C2])) - KWW * ((w2 * S.SU[C2]) * x4);
+          const double v = 0.5 * (t1 * (S.F1[C2] - S.F1D[C2])) - KW * ((w2 * S.SU[C2]) * x4);
 #else
           const double ad = andiff(S.F1D[C2], S.F1[C2], S.WR[C2], IRHOW);
           const double x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
           const double v = ad - across(x, S.WR[C2], S.SU[C2]) * IRHO;
-          W2_2 = k_is_1 ? 0.0 : v;
 #endif
+          W2_2 = k_is_1 ? 0.0 : v;  // www(:,:,:,1) = 0 (:586)
         }
         const double W2u = UP_C(W2_2);
         // :596-597

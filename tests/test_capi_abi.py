@@ -75,3 +75,26 @@ def test_no_cpu_fallback_in_product(mpdata):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in src and "from oracle" not in src, fn
                 assert "libmpdata_oracle" not in src, fn
+
+
+def test_default_kernels_do_not_spill():
+    """The x-marching kernels must fit their register budget (128 VGPRs, 4 waves per
+    SIMD): a spill shows up as scratch traffic on top of the algorithmic HBM bytes.
+    The build writes hipcc's -Rpass-analysis=kernel-resource-usage report next to the
+    objects."""
+    import glob
+    reports = glob.glob(os.path.join(ROOT, "codesign-kernels_amd", "csrc", "mpdata_kernels_*.usage.txt"))
+    reports = [r for r in reports if re.fullmatch(r"mpdata_kernels_(exact|fast)\.usage\.txt", os.path.basename(r))]
+    if not reports:
+        pytest.skip("no resource-usage report (library not built here)")
+    seen = 0
+    for rep in reports:
+        text = open(rep).read()
+        for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
+                             text, flags=re.S):
+            name, scratch, occ = m.group(1), int(m.group(2)), int(m.group(3))
+            if "xmarch" in name:
+                seen += 1
+                assert scratch == 0, f"{name} spills {scratch} bytes/lane"
+                assert occ >= 4, f"{name} occupancy {occ} waves/SIMD"
+    assert seen >= 8
