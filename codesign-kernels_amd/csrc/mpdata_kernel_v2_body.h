@@ -58,27 +58,6 @@
 namespace MPDATA_NS {
 namespace v2 {
 
-#ifndef MPD2_AUX_LD
-#define MPD2_AUX_LD 0  // cache-policy bits of the DMA loads (2 = nt)
-#endif
-#ifndef MPD2_AUX_ST
-#define MPD2_AUX_ST 0  // ... of the row stores
-#endif
-#ifndef MPD2_DIRECT_ST
-#define MPD2_DIRECT_ST 0  // 1 (experiment, per-step barrier): direct untransposed stores instead of the out tile
-#endif
-#ifndef MPD2_TRIPLE
-#define MPD2_TRIPLE 0  // 1: one barrier per three columns, 6-column LDS ring, direct (untransposed) stores
-#endif
-#ifndef MPD2_XCD_REMAP
-#define MPD2_XCD_REMAP 0
-#endif
-#ifndef MPD2_DPP
-#define MPD2_DPP 1  // vertical neighbours by DPP moves (1) or ds_bpermute (0)
-#endif
-#ifndef MPD2_USE_FULL
-#define MPD2_USE_FULL 1  // 1: condition-free body for the steady-state columns
-#endif
 
 __device__ __forceinline__ double dmax(double x, double y) { return __builtin_fmax(x, y); }
 __device__ __forceinline__ double dmin(double x, double y) { return __builtin_fmin(x, y); }
@@ -135,18 +114,7 @@ __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 #ifdef MPD2_ABL_NOMEM
   if (v != 1.2345e300) return;
 #endif
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, MPD2_AUX_ST);
-}
-
-// value of `v` held by the lane whose byte index is `addr` (= 4*lane)
-__device__ __forceinline__ double lane_get(int addr, double v) {
-#ifdef MPD2_ABL_NOPERM  // timing ablation only (wrong results)
-  return v + (double)addr;
-#endif
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_ds_bpermute(addr, lo);
-  hi = __builtin_amdgcn_ds_bpermute(addr, hi);
-  return __hiloint2double(hi, lo);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
 }
 
 // ---- vertical neighbours by DPP (register crossbar in the VALU) ---------------
@@ -172,7 +140,6 @@ __device__ __forceinline__ double shift_up(double x) { return dpp_mov<MPD_DPP_WA
 // ... with the clamps kb = max(1,k-1) / kc = min(nzm,k+1).  The move is executed by ALL
 // lanes before the select: under a divergent EXEC mask a DPP source lane that is switched
 // off counts as missing.
-template <int LPS>
 __device__ __forceinline__ double shift_dn_clamped(double x, bool k_is_1) {
   const double t = shift_dn(x);
   return k_is_1 ? x : t;
@@ -191,19 +158,11 @@ struct TileV2 {
   static constexpr int THREADS = 64 * NWV;     // = 16 * LPS
   static constexpr int RS = G_ + 1;           // out tile: LDS row stride in doubles
   static constexpr int NZM_MAX = LPS - 1;
-#if MPD2_TRIPLE
-  static constexpr int NSLOT = 6;              // input ring: the triple being computed + the next one
-#else
   static constexpr int NSLOT = 4;              // input ring: columns q .. q+3
-#endif
   static constexpr int ARR = LPS * G_;         // doubles of one array block (LPS rows x G)
   static constexpr int IN_SLOT = 3 * ARR + G_; // f,u,w rows of one column + one row of zeros
   static constexpr int OUT_SLOT = NZM_MAX * RS;
-#if MPD2_TRIPLE
-  static constexpr int LDS_DOUBLES = NSLOT * IN_SLOT;
-#else
   static constexpr int LDS_DOUBLES = NSLOT * IN_SLOT + 2 * OUT_SLOT;
-#endif
   static constexpr int VM_PER_STEP = 7;        // 1 store + 6 DMA per wave and step
 };
 
@@ -235,14 +194,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   // workgroups that share the same rows of u,w,rho,rhow,adz are dispatched together and
   // all but the first read them from the L2 / Infinity Cache instead of HBM
   const int tr = blockIdx.x;
-#if MPD2_XCD_REMAP
-  // blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): give each XCD a
-  // contiguous range of instance groups (speed only; any placement is correct)
-  const unsigned nblk = gridDim.y;
-  const unsigned grp = (nblk % 8 == 0) ? (blockIdx.y % 8) * (nblk / 8) + blockIdx.y / 8 : blockIdx.y;
-#else
   const unsigned grp = blockIdx.y;
-#endif
   const long long sl_base = (long long)grp * G;
 
   double* const f = a.f + (long long)tr * a.f_tstride;
@@ -257,10 +209,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   long long sl_c = sl_base + sl_l;
   const bool slc_ok = sl_c < ncrms;
   if (!slc_ok) sl_c = ncrms - 1;
-  // lane indices (bytes) of the vertical neighbours, clamps included
-  const int a_dn = ((k == 1 || !lvl_ok) ? lane : lane - 1) * 4;    // kb, clamped at 1
-  const int a_upc = ((k >= nzm) ? lane : lane + 1) * 4;            // kc, clamped at nzm
-  const int a_upg = ((k > nzm || kk == LPS - 1) ? lane : lane + 1) * 4;  // k+1, level nz = ghost (0)
 
   // per-lane constants (:552, :553, :565, :569)
   const double eps = (double)1.e-10f;  // :509, fp32 literal
@@ -335,17 +283,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     const unsigned cf = colb * (unsigned)(min(max(col, -2), nx + 3) + 2);
     const unsigned cu = colb * (unsigned)(min(max(col, -1), nx + 3) + 1);
     const unsigned cw = colb * (unsigned)(min(max(col, -1), nx + 2) + 1);
-#if MPD2_TRIPLE
-    double* slot = in_slot0 + ((col + 2) % 6) * T::IN_SLOT;
-#else
     double* slot = in_slot0 + (col & (T::NSLOT - 1)) * T::IN_SLOT;
-#endif
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       double* d = slot + jd[it] * 32;  // 256 bytes per instruction
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, MPD2_AUX_LD);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, MPD2_AUX_LD);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, MPD2_AUX_LD);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, 0);
     }
   };
 
@@ -388,7 +332,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr int C0 = PH, C1 = (PH + 2) % 3, C2 = (PH + 1) % 3, C3 = PH;  // slots of q, q-1, q-2, q-3
 
-#if !MPD2_TRIPLE
     // column q landed (this wave's DMA of it is 2 steps = 14 vector-memory ops
     // old), out tile of column q-4 written: then everyone's are, after the barrier
     STAMP();
@@ -400,23 +343,16 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 
     // ---- write back the column finished in the previous step (n = q-4); an
     //      inactive step stores out of range (dropped), the op count stays fixed
-#if !MPD2_DIRECT_ST
     {
       const bool act = q - 4 >= -1 && q - 4 <= nx + 2;
       st_row(rsf, (FULL || act) ? tf : OOB, colb * (unsigned)max(q - 4 + 2, 0),
              out_slot0[((q - 1) & 1) * T::OUT_SLOT + t_lds]);
     }
-#endif
     // ---- column q+3 into flight -------------------------------------------------
     dma_col(q + 3);
-#endif
 
     // ---- this column, transposed: lanes along k -------------------------------
-#if MPD2_TRIPLE
-    const double* s = in_slot0 + ((q + 2) % 6) * T::IN_SLOT;
-#else
     const double* s = in_slot0 + (q & (T::NSLOT - 1)) * T::IN_SLOT;
-#endif
     const double f0q = s[c_lds];
     const double uq = s[T::ARR + c_lds];
     const double wq = s[c_lds_w];  // ghost level: w = 0 (zero row)
@@ -425,27 +361,10 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     if (q - 3 >= -1 && q - 3 <= nx + 2 && lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = f0q + uq + wq;
     return;
 #endif
-#if MPD2_DPP == 3  // mixed: every clamped shift through the LDS crossbar, the plain ones by DPP
-#define DN_C(x) lane_get(a_dn, (x))
-#define DN_P(x) shift_dn(x)
-#define UP_C(x) lane_get(a_upc, (x))
-#define UP_G(x) shift_up(x)
-#elif MPD2_DPP == 2  // mixed: clamped up-shifts through the LDS crossbar (no VALU slot), the rest by DPP
-#define DN_C(x) shift_dn_clamped<LPS>((x), k_is_1)
-#define DN_P(x) shift_dn(x)
-#define UP_C(x) lane_get(a_upc, (x))
-#define UP_G(x) shift_up(x)
-#elif MPD2_DPP
-#define DN_C(x) shift_dn_clamped<LPS>((x), k_is_1)
+#define DN_C(x) shift_dn_clamped((x), k_is_1)
 #define DN_P(x) shift_dn(x)
 #define UP_C(x) shift_up_clamped((x), k_ge_nzm)
 #define UP_G(x) shift_up(x)
-#else
-#define DN_C(x) lane_get(a_dn, (x))
-#define DN_P(x) lane_get(a_dn, (x))
-#define UP_C(x) lane_get(a_upc, (x))
-#define UP_G(x) lane_get(a_upg, (x))
-#endif
     const double f0d = DN_C(f0q);
     const double f0u = UP_G(f0q);  // lanes above nzm load level nzm: the plain shift IS the kc clamp
     const double F0p = S.F0[C1];
@@ -583,15 +502,8 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
         double v = S.F1[C3];  // halo columns keep the first-pass value (:557)
         if (FULL || (n >= 1 && n <= nx))
           v = dmax(0.0, S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
-#if MPD2_TRIPLE || MPD2_DIRECT_ST
-        st_row(rsf, vst, colb * (unsigned)(n + 2), v);
-#else
         if (lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = v;
-#endif
       }
-#if MPD2_TRIPLE || MPD2_DIRECT_ST
-      else st_row(rsf, OOB, 0, 0.0);  // keep the vector-memory op count per step fixed
-#endif
     }
     S.U3[C2] = U3_2;
     S.DW3[C2] = DW3_2;
@@ -613,27 +525,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   // the zero row of every ring slot (never touched by the DMA)
   if (tid < T::NSLOT * G) in_slot0[(tid / G) * T::IN_SLOT + 3 * T::ARR + (tid % G)] = 0.0;
 
-#if MPD2_TRIPLE
-  // One synchronisation per three columns.  At the top of a triple: this wave's DMA of
-  // the triple's columns (issued at the top of the previous triple, followed by the three
-  // stores of that triple) has landed, everyone's has after the barrier, and all waves have
-  // left the previous triple, whose ring slots the next triple's DMA may overwrite.
-  auto triple_sync = [&](const int q0) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    dma_col(q0 + 3);
-    dma_col(q0 + 4);
-    dma_col(q0 + 5);
-  };
-  dma_col(q_first);
-  dma_col(q_first + 1);
-  dma_col(q_first + 2);
-  st_row(rsf, OOB, 0, 0.0);
-  st_row(rsf, OOB, 0, 0.0);
-  st_row(rsf, OOB, 0, 0.0);
-#define MPD_TRIPLE_SYNC(q0) triple_sync(q0)
-#else
   // columns -2, -1, 0 into flight, each behind a dropped store so that the
   // counted wait of the first steps sees the steady-state op pattern
 #pragma unroll
@@ -641,8 +532,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     st_row(rsf, OOB, 0, 0.0);
     dma_col(c);
   }
-#define MPD_TRIPLE_SYNC(q0) ((void)0)
-#endif
 
   // q advances by 3 per trip so that the ring phase is a compile-time constant.
   // Steps always run in whole triples (no step is skipped, so no ring slot stays
@@ -651,27 +540,15 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   {
     int q = q_first;
     for (; q < 4; q += 3) {  // columns -2 .. 3: pipeline fill
-      MPD_TRIPLE_SYNC(q);
       step(P0{}, Part{}, q);
       step(P1{}, Part{}, q + 1);
       step(P2{}, Part{}, q + 2);
     }
-#if MPD2_USE_FULL
     for (; q + 2 <= nx; q += 3) {  // steady state: every stage active, no conditions
-      MPD_TRIPLE_SYNC(q);
       step(P0{}, Full{}, q);
       step(P1{}, Full{}, q + 1);
       step(P2{}, Full{}, q + 2);
     }
-#endif
-#if MPD2_TRIPLE
-    for (; q <= nx + 6; q += 3) {  // remaining columns and pipeline drain
-      MPD_TRIPLE_SYNC(q);
-      step(P0{}, Part{}, q);
-      step(P1{}, Part{}, q + 1);
-      step(P2{}, Part{}, q + 2);
-    }
-#else
     // Remaining columns up to q = nx+3, the last step that computes anything (final field
     // of column nx, first-pass values of nx+1 and nx+2).  What is left after it -- three
     // columns to write back -- is done at once by the epilogue instead of by three more
@@ -715,7 +592,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
       step(P1{}, Part{}, q + 1);
       epilogue(P1{});
     }
-#endif
   }
 
 #ifdef MPD2_STAMPS

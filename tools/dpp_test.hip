@@ -5,11 +5,11 @@
 __global__ void k(double* o) {
   const int lane = threadIdx.x;
   double x = 100.0 + lane;
-  o[lane] = tst::v2::shift_dn_clamped<32>(x, false);
+  o[lane] = tst::v2::shift_dn_clamped(x, (lane % 32) == 0);
   o[64 + lane] = tst::v2::shift_dn(x);
   o[128 + lane] = tst::v2::shift_up(x);
-  o[192 + lane] = tst::v2::shift_dn_clamped<16>(x, false);
-  o[256 + lane] = tst::v2::shift_dn_clamped<64>(x, false);
+  o[192 + lane] = tst::v2::shift_dn_clamped(x, (lane % 16) == 0);
+  o[256 + lane] = tst::v2::shift_dn_clamped(x, lane == 0);
   const bool ge = (lane % 32) >= 26;
   o[320 + lane] = tst::v2::shift_up_clamped(x, ge);
   double y = x * 2.0 + o[lane];  // VALU-produced value feeding DPP
