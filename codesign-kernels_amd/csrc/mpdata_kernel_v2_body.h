@@ -270,7 +270,14 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     vdw[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 4) * row) * 8) + part;
   }
   // compute-side read position inside one array block of a slot
-  const int c_lds = (kl - 1) * G + (sl_l ^ (((kl - 1) / RPI) & (G - 1)));
+  auto lds_pos = [&](int level) __attribute__((always_inline)) {  // position of (level, this instance)
+    return (level - 1) * G + (sl_l ^ (((level - 1) / RPI) & (G - 1)));
+  };
+  const int c_lds = lds_pos(kl);
+  // the raw inputs of the vertical neighbours come straight from the staged column (an LDS
+  // read each, the kb / kc clamps live in the address) instead of a cross-lane move
+  const int c_dn = lds_pos(max(kl - 1, 1));
+  const int c_up = lds_pos(min(kl + 1, nzm));
   // w of the lanes above nzm (ghost level nz and dead lanes) is 0: they read the zero row of the slot
   const int c_lds_w = lvl_ok ? 2 * T::ARR + c_lds : 3 * T::ARR + sl_l;
 
@@ -365,8 +372,8 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 #define DN_P(x) shift_dn(x)
 #define UP_C(x) shift_up_clamped((x), k_ge_nzm)
 #define UP_G(x) shift_up(x)
-    const double f0d = DN_C(f0q);
-    const double f0u = UP_G(f0q);  // lanes above nzm load level nzm: the plain shift IS the kc clamp
+    const double f0d = s[c_dn];
+    const double f0u = s[c_up];
     const double F0p = S.F0[C1];
 
     // ================= stage A =================================================
@@ -401,11 +408,11 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     S.F0[C0] = f0q;
 
     // u / w sums for the antidiffusive cross terms (:573, :582), reference order
-    const double ud = DN_P(uq);
+    const double ud = s[T::ARR + c_dn];
     S.SU[C1] = S.UD[C1] + S.UR[C1] + uq + ud;  // u(i,kb)+u(i,k)+u(ic,k)+u(ic,kb), i = q-1
     S.UR[C0] = uq;
     S.UD[C0] = ud;
-    const double wu = UP_C(wq);
+    const double wu = s[2 * T::ARR + c_up];
     S.SW[C0] = S.PW[C1] + wq + wu;             // w(ib,k)+w(ib,kc)+w(i,k)+w(i,kc), i = q
     S.PW[C0] = wq + wu;
     S.WR[C0] = wq;
