@@ -311,18 +311,101 @@ int mpdata_plan_destroy(mpdata_plan* p) {
   return 0;
 }
 
+// Host-array call.  Optionally streamed in chunks of instances: for each chunk the strided
+// slabs of every array go host -> device (2-D copies: the chunk is cw*8 bytes of every
+// ncrms*8-byte row), the kernel advects the chunk as a problem of its own (leading
+// dimension cw), f and flux come back -- on two streams with two sets of device buffers
+// (the reference's OpenACC routine spends 72 % + 10 % of its GPU
+// time in exactly these copies, results/advect.pgiacc.17.7-nvprof:18-19).
+namespace {
+struct ChunkBufs {
+  double *f = nullptr, *u = nullptr, *w = nullptr, *rho = nullptr, *rhow = nullptr, *adz = nullptr, *flux = nullptr;
+  hipStream_t stream = nullptr;
+};
+void free_chunk(ChunkBufs& b) {
+  if (b.f) (void)hipFree(b.f);
+  if (b.u) (void)hipFree(b.u);
+  if (b.w) (void)hipFree(b.w);
+  if (b.rho) (void)hipFree(b.rho);
+  if (b.rhow) (void)hipFree(b.rhow);
+  if (b.adz) (void)hipFree(b.adz);
+  if (b.flux) (void)hipFree(b.flux);
+  if (b.stream) (void)hipStreamDestroy(b.stream);
+  b = ChunkBufs();
+}
+// Instances per chunk.  Default: the whole problem in one piece -- measured on this
+// platform, 2-D copies from PAGEABLE host arrays are staged synchronously by the runtime
+// and do not overlap anything (ncrms=65536: 42 ms in one piece vs 45 ms in 8 chunks, warm
+// pages; PCIe floor 38 ms), so chunking only pays as a bound on device memory.
+// MPDATA_HOST_CHUNK=<n> (rounded up to a multiple of 16) turns it on.
+int64_t host_chunk(int64_t ncrms) {
+  const char* v = getenv("MPDATA_HOST_CHUNK");
+  if (!v) return ncrms;
+  int64_t c = atoll(v);
+  if (c < 16) c = 16;
+  return (c + 15) / 16 * 16;
+}
+}  // namespace
+
 int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* f, const double* u,
                            const double* w, const double* rho, const double* rhow,
                            const double* adz, double* flux) {
-  if (!flux) return set_err(MPDATA_EINVAL, "null array pointer");
-  mpdata_plan* p = nullptr;
-  int rc = mpdata_plan_create(ncrms, nx, nz, ntracers, &p);
+  int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
-  rc = mpdata_plan_upload(p, f, u, w, rho, rhow, adz, flux);
-  if (!rc) rc = mpdata_plan_run(p);
-  if (!rc) rc = mpdata_plan_download(p, f, flux);
-  mpdata_plan_destroy(p);
-  return rc;
+  if (!f || !u || !w || !rho || !rhow || !adz || !flux) return set_err(MPDATA_EINVAL, "null array pointer");
+  const int64_t C = host_chunk(ncrms) < ncrms ? host_chunk(ncrms) : ncrms;
+  const int64_t nchunks = (ncrms + C - 1) / C;
+  const int nsets = nchunks > 1 ? 2 : 1;
+  const size_t nzm = (size_t)nz - 1;
+  const size_t rows_f = (size_t)(nx + 6) * nzm * ntracers, rows_u = (size_t)(nx + 5) * nzm,
+               rows_w = (size_t)(nx + 4) * nz, rows_k = nzm, rows_kz = (size_t)nz, rows_x = (size_t)nz * ntracers;
+  ChunkBufs set[2];
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < nsets && e == hipSuccess; ++i) {
+    ChunkBufs& b = set[i];
+    if (e == hipSuccess) e = hipMalloc((void**)&b.f, rows_f * C * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&b.u, rows_u * C * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&b.w, rows_w * C * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&b.rho, rows_k * C * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&b.rhow, rows_kz * C * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&b.adz, rows_k * C * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&b.flux, rows_x * C * 8);
+    if (e == hipSuccess) e = hipStreamCreate(&b.stream);
+  }
+  const size_t hp = (size_t)ncrms * 8;  // host pitch: one row of all instances
+  for (int64_t c = 0; c < nchunks && e == hipSuccess && rc == 0; ++c) {
+    ChunkBufs& b = set[c % nsets];
+    const int64_t c0 = c * C, cw = (c0 + C <= ncrms) ? C : ncrms - c0;
+    const size_t dp = (size_t)cw * 8;  // device pitch: the chunk is its own problem, ld = cw
+    auto h2d = [&](double* d, const double* h, size_t rows) {
+      if (e == hipSuccess) e = hipMemcpy2DAsync(d, dp, h + c0, hp, dp, rows, hipMemcpyHostToDevice, b.stream);
+    };
+    auto d2h = [&](double* h, const double* d, size_t rows) {
+      if (e == hipSuccess) e = hipMemcpy2DAsync(h + c0, hp, d, dp, dp, rows, hipMemcpyDeviceToHost, b.stream);
+    };
+    h2d(b.f, f, rows_f);
+    h2d(b.u, u, rows_u);
+    h2d(b.w, w, rows_w);
+    h2d(b.rho, rho, rows_k);
+    h2d(b.rhow, rhow, rows_kz);
+    h2d(b.adz, adz, rows_k);
+    h2d(b.flux, flux, rows_x);  // level nz is never written (reference :541,:624): carry it through
+    if (e != hipSuccess) break;
+    rc = mpdata_advect_scalar2d_device(cw, nx, nz, ntracers, b.f, b.u, b.w, b.rho, b.rhow, b.adz, b.flux,
+                                       (void*)b.stream);
+    if (rc) break;
+    d2h(f, b.f, rows_f);
+    d2h(flux, b.flux, rows_x);
+  }
+  for (int i = 0; i < nsets; ++i)
+    if (set[i].stream) {
+      hipError_t e2 = hipStreamSynchronize(set[i].stream);
+      if (e == hipSuccess) e = e2;
+    }
+  for (int i = 0; i < nsets; ++i) free_chunk(set[i]);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_err(e, "mpdata_advect_scalar2d (streamed host call)");
+  return 0;
 }
 
 int mpdata_fill_synthetic_device(double* a, int sid, int64_t rows, int64_t ncrms_global,
