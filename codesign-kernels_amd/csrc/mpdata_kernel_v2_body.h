@@ -137,17 +137,30 @@ __device__ __forceinline__ double dpp_mov(double src) {
 __device__ __forceinline__ double shift_dn(double x) { return dpp_mov<MPD_DPP_WAVE_SHR1>(x); }
 // value of lane+1 (level k+1); lane 63 reads 0
 __device__ __forceinline__ double shift_up(double x) { return dpp_mov<MPD_DPP_WAVE_SHL1>(x); }
-// ... with the clamps kb = max(1,k-1) / kc = min(nzm,k+1).  The move is executed by ALL
-// lanes before the select: under a divergent EXEC mask a DPP source lane that is switched
-// off counts as missing.
-__device__ __forceinline__ double shift_dn_clamped(double x, bool k_is_1) {
-  const double t = shift_dn(x);
-  return k_is_1 ? x : t;
+// ... with the clamps kb = max(1,k-1) / kc = min(nzm,k+1): `own` is the wave mask of the
+// lanes that keep their own value.  Select and move are ONE instruction per 32-bit half
+// (v_cndmask_b32 with a DPP source operand; hipcc emits v_mov_b32_dpp + v_cndmask_b32 for
+// the same thing written in C).  s_nop 1: a DPP operand written by the preceding VALU
+// instruction needs two wait states, which the compiler cannot see inside an asm block.
+// Executed by ALL lanes (under a divergent EXEC mask a switched-off source lane counts as
+// missing).
+#define MPD_CNDMASK_DPP(CTRL)                                                                  \
+  int lo, hi;                                                                                  \
+  const int xl = __double2loint(x), xh = __double2hiint(x);                                    \
+  asm("s_mov_b64 vcc, %4\n\ts_nop 1\n\t"                                                      \
+      "v_cndmask_b32_dpp %0, %2, %2, vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+      "v_cndmask_b32_dpp %1, %3, %3, vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0"      \
+      : "=&v"(lo), "=&v"(hi)                                                                   \
+      : "v"(xl), "v"(xh), "s"(own)                                                             \
+      : "vcc");                                                                                \
+  return __hiloint2double(hi, lo);
+__device__ __forceinline__ double shift_dn_clamped(double x, unsigned long long own) {
+  MPD_CNDMASK_DPP("wave_shr:1")
 }
-__device__ __forceinline__ double shift_up_clamped(double x, bool top) {
-  const double t = shift_up(x);
-  return top ? x : t;
+__device__ __forceinline__ double shift_up_clamped(double x, unsigned long long own) {
+  MPD_CNDMASK_DPP("wave_shl:1")
 }
+#undef MPD_CNDMASK_DPP
 
 template <int LPS, int G_>
 struct TileV2 {
@@ -223,11 +236,15 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   // exponent step on dd*(...) (exact scaling, bit-identical)
   const int dd_exp = (k == 1 || k == nzm) ? 1 : 0;
 #ifdef MPDATA_FAST_DIV
-  const double KW = 0.03125 * IRHO;
-  const double KU = __builtin_ldexp(KW * IADZ, dd_exp);
+  const double KU = __builtin_ldexp(0.03125 * IRHO * IADZ, dd_exp);
+  // www(:,:,:,1) = 0 (:586) lives in the constant: at k = 1 the advective part of W2 is an
+  // exact zero already (kb = k, f - f(kb) = 0), a zero KW removes the cross part
+  const double KW = (k == 1) ? 0.0 : 0.03125 * IRHO;
 #endif
   const bool k_is_1 = k == 1;
   const bool k_ge_nzm = k >= nzm;
+  const unsigned long long own_dn = __builtin_amdgcn_ballot_w64(k_is_1);     // kb = k
+  const unsigned long long own_up = __builtin_amdgcn_ballot_w64(k_ge_nzm);   // kc = k
 
   // ---- write-back mapping: thread -> (row = level, instance) -----------------
   const int t_row = tid / G;  // level index k-1 of the row this thread stores
@@ -368,9 +385,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     if (q - 3 >= -1 && q - 3 <= nx + 2 && lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = f0q + uq + wq;
     return;
 #endif
-#define DN_C(x) shift_dn_clamped((x), k_is_1)
+#define DN_C(x) shift_dn_clamped((x), own_dn)
 #define DN_P(x) shift_dn(x)
-#define UP_C(x) shift_up_clamped((x), k_ge_nzm)
+#define UP_C(x) shift_up_clamped((x), own_up)
 #define UP_G(x) shift_up(x)
     const double f0d = s[c_dn];
     const double f0u = s[c_up];
@@ -409,12 +426,19 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 
     // u / w sums for the antidiffusive cross terms (:573, :582), reference order
     const double ud = s[T::ARR + c_dn];
-    S.SU[C1] = S.UD[C1] + S.UR[C1] + uq + ud;  // u(i,kb)+u(i,k)+u(ic,k)+u(ic,kb), i = q-1
-    S.UR[C0] = uq;
-    S.UD[C0] = ud;
     const double wu = s[2 * T::ARR + c_up];
+#ifdef MPDATA_FAST_DIV
+    S.UD[C0] = uq + ud;                        // (the ring holds the pair sum here)
+    S.SU[C1] = S.UD[C1] + S.UD[C0];
+    S.PW[C0] = wq + wu;
+    S.SW[C0] = S.PW[C1] + S.PW[C0];
+#else
+    S.SU[C1] = S.UD[C1] + S.UR[C1] + uq + ud;  // u(i,kb)+u(i,k)+u(ic,k)+u(ic,kb), i = q-1
+    S.UD[C0] = ud;
     S.SW[C0] = S.PW[C1] + wq + wu;             // w(ib,k)+w(ib,kc)+w(i,k)+w(i,kc), i = q
     S.PW[C0] = wq + wu;
+#endif
+    S.UR[C0] = uq;
     S.WR[C0] = wq;
 
     STAMP();
@@ -443,13 +467,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
           const double w2 = S.WR[C2];
           const double t1 = __builtin_fabs(w2) - (w2 * w2) * IRHOW;
           const double x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
-          const double v = 0.5 * (t1 * (S.F1[C2] - S.F1D[C2])) - KW * ((w2 * S.SU[C2]) * x4);
+          W2_2 = 0.5 * (t1 * (S.F1[C2] - S.F1D[C2])) - KW * ((w2 * S.SU[C2]) * x4);  // k = 1: 0
 #else
           const double ad = andiff(S.F1D[C2], S.F1[C2], S.WR[C2], IRHOW);
           const double x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
           const double v = ad - across(x, S.WR[C2], S.SU[C2]) * IRHO;
-#endif
           W2_2 = k_is_1 ? 0.0 : v;  // www(:,:,:,1) = 0 (:586)
+#endif
         }
         const double W2u = UP_C(W2_2);
         // :596-597
