@@ -16,13 +16,25 @@ compile -- no reference source text is written into this repository:
                                               adz,f,u,w,rho,rhow,flux)
   3. after :49 (call advect_scalar2D_cpu)  -> stream-binary dump of f, flux
                                               to ./mpdata_out.bin
+  4. (fp32 builds only) :12-13             -> the reference's precision switch:
+                                              the (13) line is commented and rp
+                                              becomes selected_real_kind(6).
+                                              NOTE: the reference's own "single
+                                              precision" line asks for
+                                              selected_real_kind(7), which is
+                                              kind 8 (fp64) under flang and
+                                              every compiler whose fp32 has
+                                              precision() = 6 -- flipping the
+                                              switch as written reproduces the
+                                              fp64 build.  (6) is what yields
+                                              IEEE fp32, the evident intent.
 
 The arithmetic body (:477-642) is untouched.  Flags: `amdflang -O3
 -ffp-contract=off` (flang does not re-associate; -O0 and -O3 agree bitwise,
 SURVEY.md section 8c).  The executable still prints the reference's own
 `CPU Timing:` line (:640), which bench.py's cpu_baseline leg parses.
 
-Usage:  python oracle/build_ref.py NCRMS NX NZ [NCRMS NX NZ ...]
+Usage:  python oracle/build_ref.py [--f32] NCRMS NX NZ [NCRMS NX NZ ...]
 Needs /root/reference and amdflang; on the GPU box neither is used -- the
 prebuilt oracle/_ref binaries travel with the snapshot.
 """
@@ -39,11 +51,11 @@ OUT_DIR = os.path.join(HERE, "_ref")
 FC = shutil.which("amdflang") or "/opt/rocm/bin/amdflang"
 
 
-def ref_exe_path(ncrms, nx, nz):
-    return os.path.join(OUT_DIR, f"advect_ref_{ncrms}x{nx}x{nz}")
+def ref_exe_path(ncrms, nx, nz, f32=False):
+    return os.path.join(OUT_DIR, f"advect_ref_{ncrms}x{nx}x{nz}" + ("_f32" if f32 else ""))
 
 
-def _patched_lines(ncrms, nx, nz):
+def _patched_lines(ncrms, nx, nz, f32=False):
     with open(REF_SRC) as fh:
         lines = fh.read().split("\n")
 
@@ -59,6 +71,12 @@ def _patched_lines(ncrms, nx, nz):
     lines[6] = f"  integer, parameter :: nslices = {ncrms}"
     lines[7] = f"  integer, parameter :: nz      = {nz}"
     lines[8] = f"  integer, parameter :: nx      = {nx}"
+    # 4. precision (:11-12)
+    if f32:
+        expect(12, r"^\s*!\s*integer, parameter :: rp\s*=\s*selected_real_kind\(7\)")
+        expect(13, r"^\s*integer, parameter :: rp\s*=\s*selected_real_kind\(13\)")
+        lines[11] = "  integer, parameter :: rp      = selected_real_kind(6)"
+        lines[12] = " !integer, parameter :: rp      = selected_real_kind(13)"
     # 2. inputs (:654-660): same arrays, same order, read instead of drawn
     names = ["adz", "f", "u", "w", "rho", "rhow", "flux"]
     for off, name in enumerate(names):
@@ -76,9 +94,9 @@ def _patched_lines(ncrms, nx, nz):
     return "\n".join(lines)
 
 
-def build(ncrms, nx, nz, force=False):
-    """Build oracle/_ref/advect_ref_<shape>; returns its path."""
-    exe = ref_exe_path(ncrms, nx, nz)
+def build(ncrms, nx, nz, force=False, f32=False):
+    """Build oracle/_ref/advect_ref_<shape>[_f32]; returns its path."""
+    exe = ref_exe_path(ncrms, nx, nz, f32)
     if os.path.exists(exe) and not force:
         return exe
     if not os.path.exists(REF_SRC):
@@ -89,10 +107,10 @@ def build(ncrms, nx, nz, force=False):
     try:
         src = os.path.join(tmp, "ref_patched.F90")
         with open(src, "w") as fh:
-            fh.write(_patched_lines(ncrms, nx, nz))
+            fh.write(_patched_lines(ncrms, nx, nz, f32))
         flags = ["-O3", "-ffp-contract=off"]
         # statics (f,u,w + their _save copies) beyond 2 GB need the medium model
-        static_bytes = 2 * 8 * ncrms * ((nx + 6) + (nx + 5)) * (nz - 1) + 2 * 8 * ncrms * (nx + 4) * nz
+        static_bytes = 2 * (4 if f32 else 8) * ncrms * ((nx + 6) + (nx + 5)) * (nz - 1) + 2 * (4 if f32 else 8) * ncrms * (nx + 4) * nz
         if static_bytes > 1.5e9:
             flags.append("-mcmodel=medium")
         subprocess.run([FC, *flags, "-o", exe, src], check=True, cwd=tmp)
@@ -102,8 +120,9 @@ def build(ncrms, nx, nz, force=False):
 
 
 if __name__ == "__main__":
-    args = [int(a) for a in sys.argv[1:]]
+    f32 = "--f32" in sys.argv[1:]
+    args = [int(a) for a in sys.argv[1:] if a != "--f32"]
     if not args or len(args) % 3:
         sys.exit(__doc__)
     for j in range(0, len(args), 3):
-        print(build(*args[j:j + 3], force=True))
+        print(build(*args[j:j + 3], force=True, f32=f32))

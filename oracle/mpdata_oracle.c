@@ -1,7 +1,7 @@
 /*
  * oracle/mpdata_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
- * CPU restatement (plain C, fp64) of the E3SM-MMF 2D MPDATA tracer advection
+ * CPU restatement (plain C; fp64, and fp32 with -DMPDATA_ORACLE_F32) of the E3SM-MMF 2D MPDATA tracer advection
  * routine of the reference:
  *   mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:477-642
  *   (subroutine advect_scalar2D_cpu; constants/statement functions :500-510).
@@ -33,6 +33,22 @@
 #include <omp.h>
 #endif
 
+/* Precision: the reference switches `rp` between selected_real_kind(13) and (7)
+ * (reference :12-13).  This file is compiled twice: as is (fp64, the symbols below) and
+ * with -DMPDATA_ORACLE_F32 (fp32, every exported symbol gets the suffix _f32).  In the
+ * fp32 build every literal is an fp32 value, as every default-real literal of the
+ * reference then is. */
+#ifdef MPDATA_ORACLE_F32
+typedef float real;
+#define RABS fabsf
+#define SYM(name) name##_f32
+#else
+typedef double real;
+#define RABS fabs
+#define SYM(name) name
+#endif
+#define R_(x) ((real)(x))
+
 typedef struct {
   int64_t n;      /* ncrms (leading dimension of every array) */
   int nx, nz, nzm;
@@ -48,32 +64,32 @@ typedef struct {
 #define WWW_(sl, i, k) www[(sl) + d.n * ((int64_t)((i) + 1) + (int64_t)(d.nx + 4) * ((k) - 1))]
 #define K2_(a, sl, k)  a  [(sl) + d.n * (int64_t)((k) - 1)]
 
-static inline double dmax(double a, double b) { return a > b ? a : b; }
-static inline double dmin(double a, double b) { return a < b ? a : b; }
+static inline real dmax(real a, real b) { return a > b ? a : b; }
+static inline real dmin(real a, real b) { return a < b ? a : b; }
 /* Statement functions, reference :500-503 (left-to-right association). */
-static inline double andiff(double x1, double x2, double a, double b) {
-  return (fabs(a) - a * a * b) * 0.5 * (x2 - x1);
+static inline real andiff(real x1, real x2, real a, real b) {
+  return (RABS(a) - a * a * b) * R_(0.5) * (x2 - x1);
 }
-static inline double across(double x1, double a1, double a2) {
-  return 0.03125 * a1 * a2 * x1;
+static inline real across(real x1, real a1, real a2) {
+  return R_(0.03125) * a1 * a2 * x1;
 }
-static inline double pp(double y) { return dmax(0.0, y); }
-static inline double pn(double y) { return -dmin(0.0, y); }
+static inline real pp(real y) { return dmax(R_(0.0), y); }
+static inline real pn(real y) { return -dmin(R_(0.0), y); }
 
 /* Scratch = the reference's automatic arrays (:485-491), heap allocated. */
 typedef struct {
-  double *mx, *mn, *uuu, *www, *iadz, *irho, *irhow;
+  real *mx, *mn, *uuu, *www, *iadz, *irho, *irhow;
 } scratch_t;
 
 static int scratch_alloc(scratch_t *s, dims_t d) {
   size_t n = (size_t)d.n;
-  s->mx = (double *)malloc(n * (d.nx + 2) * d.nzm * sizeof(double));
-  s->mn = (double *)malloc(n * (d.nx + 2) * d.nzm * sizeof(double));
-  s->uuu = (double *)malloc(n * (d.nx + 5) * d.nzm * sizeof(double));
-  s->www = (double *)malloc(n * (d.nx + 4) * d.nz * sizeof(double));
-  s->iadz = (double *)malloc(n * d.nzm * sizeof(double));
-  s->irho = (double *)malloc(n * d.nzm * sizeof(double));
-  s->irhow = (double *)malloc(n * d.nzm * sizeof(double));
+  s->mx = (real *)malloc(n * (d.nx + 2) * d.nzm * sizeof(real));
+  s->mn = (real *)malloc(n * (d.nx + 2) * d.nzm * sizeof(real));
+  s->uuu = (real *)malloc(n * (d.nx + 5) * d.nzm * sizeof(real));
+  s->www = (real *)malloc(n * (d.nx + 4) * d.nz * sizeof(real));
+  s->iadz = (real *)malloc(n * d.nzm * sizeof(real));
+  s->irho = (real *)malloc(n * d.nzm * sizeof(real));
+  s->irhow = (real *)malloc(n * d.nzm * sizeof(real));
   return (s->mx && s->mn && s->uuu && s->www && s->iadz && s->irho && s->irhow) ? 0 : -1;
 }
 static void scratch_free(scratch_t *s) {
@@ -86,22 +102,22 @@ static void scratch_free(scratch_t *s) {
  * statement of the reference couples different sl, so running it per
  * sl-range is the same arithmetic in the same order for every element.
  */
-static void advect_range(dims_t d, int64_t s0, int64_t s1, double *f, const double *u,
-                         const double *w, const double *rho, const double *rhow,
-                         const double *adz, double *flux, scratch_t sc) {
-  double *mx = sc.mx, *mn = sc.mn, *uuu = sc.uuu, *www = sc.www;
-  double *iadz = sc.iadz, *irho = sc.irho, *irhow = sc.irhow;
+static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *u,
+                         const real *w, const real *rho, const real *rhow,
+                         const real *adz, real *flux, scratch_t sc) {
+  real *mx = sc.mx, *mn = sc.mn, *uuu = sc.uuu, *www = sc.www;
+  real *iadz = sc.iadz, *irho = sc.irho, *irhow = sc.irhow;
   const int nx = d.nx, nz = d.nz, nzm = d.nzm;
   const int nxp1 = nx + 1, nxp2 = nx + 2, nxp3 = nx + 3;
   /* reference :509 -- `eps = 1.e-10` is a default-real (fp32) literal
    * assigned to an fp64 variable. */
-  const double eps = (double)1.e-10f;
+  const real eps = (real)1.e-10f;
   int i, k, kc, kb, ib, ic;
   int64_t sl;
 
   /* :511  www(:,:,:,nz)=0. */
   for (i = -1; i <= nxp2; i++)
-    for (sl = s0; sl < s1; sl++) WWW_(sl, i, nz) = 0.0;
+    for (sl = s0; sl < s1; sl++) WWW_(sl, i, nz) = R_(0.0);
 
   /* :513-526  pass-0 extrema (nonos is hard-wired .true., :508) */
   for (k = 1; k <= nzm; k++) {
@@ -120,11 +136,11 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, double *f, const doub
     kb = k - 1 > 1 ? k - 1 : 1;
     for (i = -1; i <= nxp3; i++)
       for (sl = s0; sl < s1; sl++)
-        UUU_(sl, i, k) = dmax(0.0, U_(sl, i, k)) * F_(sl, i - 1, k) + dmin(0.0, U_(sl, i, k)) * F_(sl, i, k);
+        UUU_(sl, i, k) = dmax(R_(0.0), U_(sl, i, k)) * F_(sl, i - 1, k) + dmin(R_(0.0), U_(sl, i, k)) * F_(sl, i, k);
     for (i = -1; i <= nxp2; i++)
       for (sl = s0; sl < s1; sl++)
-        WWW_(sl, i, k) = dmax(0.0, W_(sl, i, k)) * F_(sl, i, kb) + dmin(0.0, W_(sl, i, k)) * F_(sl, i, k);
-    for (sl = s0; sl < s1; sl++) K2_(flux, sl, k) = 0.0;
+        WWW_(sl, i, k) = dmax(R_(0.0), W_(sl, i, k)) * F_(sl, i, kb) + dmin(R_(0.0), W_(sl, i, k)) * F_(sl, i, k);
+    for (sl = s0; sl < s1; sl++) K2_(flux, sl, k) = R_(0.0);
     for (i = 1; i <= nx; i++)
       for (sl = s0; sl < s1; sl++) K2_(flux, sl, k) = K2_(flux, sl, k) + WWW_(sl, i, k);
   }
@@ -132,8 +148,8 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, double *f, const doub
   /* :550-560  first-pass update, halo columns -1..nx+2 included */
   for (k = 1; k <= nzm; k++) {
     for (sl = s0; sl < s1; sl++) {
-      K2_(irho, sl, k) = 1.0 / K2_(rho, sl, k);
-      K2_(iadz, sl, k) = 1.0 / K2_(adz, sl, k);
+      K2_(irho, sl, k) = R_(1.0) / K2_(rho, sl, k);
+      K2_(iadz, sl, k) = R_(1.0) / K2_(adz, sl, k);
     }
     for (i = -1; i <= nxp2; i++)
       for (sl = s0; sl < s1; sl++)
@@ -146,11 +162,11 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, double *f, const doub
     kc = k + 1 < nzm ? k + 1 : nzm;
     kb = k - 1 > 1 ? k - 1 : 1;
     /* :569  `2./(kc-kb)` is default-real / integer: exactly 1.0 or 2.0 */
-    const double two_over = (double)(2.0f / (float)(kc - kb));
-    for (sl = s0; sl < s1; sl++) K2_(irhow, sl, k) = 1.0 / (K2_(rhow, sl, k) * K2_(adz, sl, k));
+    const real two_over = (real)(2.0f / (float)(kc - kb));
+    for (sl = s0; sl < s1; sl++) K2_(irhow, sl, k) = R_(1.0) / (K2_(rhow, sl, k) * K2_(adz, sl, k));
     for (i = 0; i <= nxp2; i++)
       for (sl = s0; sl < s1; sl++) {
-        const double dd = two_over / K2_(adz, sl, k);
+        const real dd = two_over / K2_(adz, sl, k);
         ib = i - 1;
         UUU_(sl, i, k) = andiff(F_(sl, ib, k), F_(sl, i, k), U_(sl, i, k), K2_(irho, sl, k)) -
                          across(dd * (F_(sl, ib, kc) + F_(sl, i, kc) - F_(sl, ib, kb) - F_(sl, i, kb)),
@@ -168,7 +184,7 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, double *f, const doub
   }
   /* :586  www(:,:,:,1) = 0. */
   for (i = -1; i <= nxp2; i++)
-    for (sl = s0; sl < s1; sl++) WWW_(sl, i, 1) = 0.0;
+    for (sl = s0; sl < s1; sl++) WWW_(sl, i, 1) = R_(0.0);
 
   /* :588-600  pass-1 extrema */
   for (k = 1; k <= nzm; k++) {
@@ -201,13 +217,13 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, double *f, const doub
     for (i = 1; i <= nxp1; i++)
       for (sl = s0; sl < s1; sl++) {
         ib = i - 1;
-        UUU_(sl, i, k) = pp(UUU_(sl, i, k)) * dmin(dmin(1.0, MX_(sl, i, k)), MN_(sl, ib, k)) -
-                         pn(UUU_(sl, i, k)) * dmin(dmin(1.0, MX_(sl, ib, k)), MN_(sl, i, k));
+        UUU_(sl, i, k) = pp(UUU_(sl, i, k)) * dmin(dmin(R_(1.0), MX_(sl, i, k)), MN_(sl, ib, k)) -
+                         pn(UUU_(sl, i, k)) * dmin(dmin(R_(1.0), MX_(sl, ib, k)), MN_(sl, i, k));
       }
     for (i = 1; i <= nx; i++)
       for (sl = s0; sl < s1; sl++) {
-        WWW_(sl, i, k) = pp(WWW_(sl, i, k)) * dmin(dmin(1.0, MX_(sl, i, k)), MN_(sl, i, kb)) -
-                         pn(WWW_(sl, i, k)) * dmin(dmin(1.0, MX_(sl, i, kb)), MN_(sl, i, k));
+        WWW_(sl, i, k) = pp(WWW_(sl, i, k)) * dmin(dmin(R_(1.0), MX_(sl, i, k)), MN_(sl, i, kb)) -
+                         pn(WWW_(sl, i, k)) * dmin(dmin(R_(1.0), MX_(sl, i, kb)), MN_(sl, i, k));
         K2_(flux, sl, k) = K2_(flux, sl, k) + WWW_(sl, i, k);
       }
   }
@@ -216,7 +232,7 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, double *f, const doub
   for (k = 1; k <= nzm; k++)
     for (i = 1; i <= nx; i++)
       for (sl = s0; sl < s1; sl++)
-        F_(sl, i, k) = dmax(0.0, F_(sl, i, k) - (UUU_(sl, i + 1, k) - UUU_(sl, i, k) +
+        F_(sl, i, k) = dmax(R_(0.0), F_(sl, i, k) - (UUU_(sl, i + 1, k) - UUU_(sl, i, k) +
                                                  (WWW_(sl, i, k + 1) - WWW_(sl, i, k)) * K2_(iadz, sl, k)) * K2_(irho, sl, k));
 }
 
@@ -227,9 +243,9 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, double *f, const doub
  * sl-chunks (this build's own addition; the reference is serial), same
  * arithmetic per element.  Returns 0, or -1 on bad sizes / allocation failure.
  */
-int mpdata_oracle_advect(int64_t ncrms, int nx, int nz, double *f, const double *u,
-                         const double *w, const double *rho, const double *rhow,
-                         const double *adz, double *flux, int nthreads) {
+int SYM(mpdata_oracle_advect)(int64_t ncrms, int nx, int nz, real *f, const real *u,
+                         const real *w, const real *rho, const real *rhow,
+                         const real *adz, real *flux, int nthreads) {
   dims_t d;
   scratch_t sc;
   if (ncrms < 1 || nx < 1 || nz < 3) return -1;
@@ -256,21 +272,21 @@ int mpdata_oracle_advect(int64_t ncrms, int nx, int nz, double *f, const double 
 /* Tracer-batched semantics (not in the reference): the result
  * of calling the routine once per tracer with the same u,w,rho,rhow,adz.
  * f(ncrms,-2:nx+3,1,nzm,ntracers), flux(ncrms,nz,ntracers). */
-int mpdata_oracle_advect_tracers(int64_t ncrms, int nx, int nz, int ntracers, double *f,
-                                 const double *u, const double *w, const double *rho,
-                                 const double *rhow, const double *adz, double *flux,
+int SYM(mpdata_oracle_advect_tracers)(int64_t ncrms, int nx, int nz, int ntracers, real *f,
+                                 const real *u, const real *w, const real *rho,
+                                 const real *rhow, const real *adz, real *flux,
                                  int nthreads) {
   int t, rc = 0;
   const int64_t fstride = ncrms * (int64_t)(nx + 6) * (nz - 1);
   const int64_t xstride = ncrms * (int64_t)nz;
   if (ntracers < 1) return -1;
   for (t = 0; t < ntracers && rc == 0; t++)
-    rc = mpdata_oracle_advect(ncrms, nx, nz, f + t * fstride, u, w, rho, rhow, adz,
+    rc = SYM(mpdata_oracle_advect)(ncrms, nx, nz, f + t * fstride, u, w, rho, rhow, adz,
                               flux + t * xstride, nthreads);
   return rc;
 }
 
-int mpdata_oracle_max_threads(void) {
+int SYM(mpdata_oracle_max_threads)(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
 #else
@@ -290,13 +306,14 @@ int mpdata_oracle_max_threads(void) {
  * dist 3 "raw-signed": as 2 but u,w = r-0.5
  * A shard [sl0, sl0+nloc) of a global ncrms is generated with the GLOBAL
  * index, so shards of any partition reproduce the unsharded data.
+ * The fp32 build rounds the same fp64 value to fp32.
  */
 static inline uint64_t mix64(uint64_t z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-void mpdata_oracle_fill(double *a, int sid, int64_t rows, int64_t ncrms_global, int64_t sl0,
+void SYM(mpdata_oracle_fill)(real *a, int sid, int64_t rows, int64_t ncrms_global, int64_t sl0,
                         int64_t nloc, uint64_t seed, int dist) {
   const uint64_t base = seed + (uint64_t)sid * 0xD1B54A32D192ED03ull;
   double shift = 0.0;
@@ -311,6 +328,6 @@ void mpdata_oracle_fill(double *a, int sid, int64_t rows, int64_t ncrms_global, 
     for (s = 0; s < nloc; s++) {
       uint64_t j = (uint64_t)(r * ncrms_global + sl0 + s);
       uint64_t z = mix64(base + (j + 1) * 0x9E3779B97F4A7C15ull);
-      a[r * nloc + s] = (double)(z >> 11) * 0x1.0p-53 + shift;
+      a[r * nloc + s] = (real)((double)(z >> 11) * 0x1.0p-53 + shift);
     }
 }

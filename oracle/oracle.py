@@ -36,8 +36,13 @@ def build_lib(force=False):
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= os.path.getmtime(src)):
         return LIB_PATH
-    subprocess.run(["gcc", "-O3", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared",
-                    "-o", LIB_PATH, src, "-lm"], check=True)
+    # compiled twice into one library: fp64 symbols, and fp32 symbols (suffix _f32)
+    flags = ["-O3", "-ffp-contract=off", "-fopenmp", "-fPIC"]
+    with tempfile.TemporaryDirectory(prefix="mpdata_oracle_") as tmp:
+        o64, o32 = os.path.join(tmp, "o64.o"), os.path.join(tmp, "o32.o")
+        subprocess.run(["gcc", *flags, "-c", "-o", o64, src], check=True)
+        subprocess.run(["gcc", *flags, "-DMPDATA_ORACLE_F32", "-c", "-o", o32, src], check=True)
+        subprocess.run(["gcc", "-shared", "-fopenmp", "-o", LIB_PATH, o64, o32, "-lm"], check=True)
     return LIB_PATH
 
 
@@ -60,13 +65,27 @@ def lib():
         L.mpdata_oracle_fill.argtypes = [dp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64,
                                          ctypes.c_int]
+        fp = ctypes.POINTER(ctypes.c_float)
+        L.mpdata_oracle_advect_f32.restype = ctypes.c_int
+        L.mpdata_oracle_advect_f32.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                               fp, fp, fp, fp, fp, fp, fp, ctypes.c_int]
+        L.mpdata_oracle_advect_tracers_f32.restype = ctypes.c_int
+        L.mpdata_oracle_advect_tracers_f32.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.c_int, fp, fp, fp, fp, fp, fp, fp,
+                                                       ctypes.c_int]
+        L.mpdata_oracle_fill_f32.restype = None
+        L.mpdata_oracle_fill_f32.argtypes = [fp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64,
+                                             ctypes.c_int]
         _lib = L
     return _lib
 
 
 def _dp(a):
-    assert a.dtype == np.float64 and a.flags["F_CONTIGUOUS"]
-    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    """ctypes pointer to a Fortran-ordered fp64 or fp32 array."""
+    assert a.dtype in (np.float64, np.float32) and a.flags["F_CONTIGUOUS"]
+    ct = ctypes.c_double if a.dtype == np.float64 else ctypes.c_float
+    return a.ctypes.data_as(ctypes.POINTER(ct))
 
 
 def shapes(ncrms, nx, nz, ntracers=1):
@@ -91,10 +110,11 @@ def _mix64(z):
     return z ^ (z >> np.uint64(31))
 
 
-def fill_array(name, shape, seed, dist, ncrms_global=None, sl0=0):
+def fill_array(name, shape, seed, dist, ncrms_global=None, sl0=0, dtype=np.float64):
     """numpy version of mpdata_oracle_fill: one input array, Fortran order.
     shape[0] is the local ncrms; ncrms_global/sl0 place it inside a larger
-    (sharded) problem."""
+    (sharded) problem.  dtype float32 rounds the fp64 value (reference precision
+    switch :11-12)."""
     nloc = shape[0]
     rows = int(np.prod(shape[1:], dtype=np.int64))
     ng = nloc if ncrms_global is None else ncrms_global
@@ -111,24 +131,25 @@ def fill_array(name, shape, seed, dist, ncrms_global=None, sl0=0):
         shift = {2: -0.5, 3: -0.5, 0: 0.5, 4: 0.5, 5: 0.5}.get(sid, 0.0)
     elif dist == DIST_RAW_SIGNED:
         shift = {2: -0.5, 3: -0.5}.get(sid, 0.0)
-    out = out + shift
+    out = (out + shift).astype(dtype)
     return np.asfortranarray(out.reshape(shape, order="F"))
 
 
 def make_inputs(ncrms, nx, nz, seed=100, dist=DIST_CONDITIONED, ntracers=1,
-                ncrms_global=None, sl0=0):
-    """All seven arrays as a dict of Fortran-ordered float64 arrays."""
+                ncrms_global=None, sl0=0, dtype=np.float64):
+    """All seven arrays as a dict of Fortran-ordered float64 (or float32) arrays."""
     sh = shapes(ncrms, nx, nz, ntracers)
-    return {k: fill_array(k, sh[k], seed, dist, ncrms_global, sl0) for k in SID}
+    return {k: fill_array(k, sh[k], seed, dist, ncrms_global, sl0, dtype) for k in SID}
 
 
-def fill_array_c(name, shape, seed, dist, ncrms_global=None, sl0=0):
-    """The C generator (mpdata_oracle_fill); must equal fill_array bitwise."""
+def fill_array_c(name, shape, seed, dist, ncrms_global=None, sl0=0, dtype=np.float64):
+    """The C generator (mpdata_oracle_fill[_f32]); must equal fill_array bitwise."""
     nloc = shape[0]
     rows = int(np.prod(shape[1:], dtype=np.int64))
-    a = np.empty(shape, dtype=np.float64, order="F")
-    lib().mpdata_oracle_fill(_dp(a), SID[name], rows, nloc if ncrms_global is None else ncrms_global,
-                             sl0, nloc, seed, dist)
+    a = np.empty(shape, dtype=dtype, order="F")
+    fn = lib().mpdata_oracle_fill if a.dtype == np.float64 else lib().mpdata_oracle_fill_f32
+    fn(_dp(a), SID[name], rows, nloc if ncrms_global is None else ncrms_global, sl0, nloc,
+       seed, dist)
     return a
 
 
@@ -142,10 +163,11 @@ def advect(inp, nthreads=1):
     nx, nz = nxp6 - 6, nzm + 1
     args = (_dp(f), _dp(inp["u"]), _dp(inp["w"]), _dp(inp["rho"]), _dp(inp["rhow"]),
             _dp(inp["adz"]), _dp(flux), nthreads)
+    sfx = "" if f.dtype == np.float64 else "_f32"
     if nt == 1:
-        rc = lib().mpdata_oracle_advect(ncrms, nx, nz, *args)
+        rc = getattr(lib(), "mpdata_oracle_advect" + sfx)(ncrms, nx, nz, *args)
     else:
-        rc = lib().mpdata_oracle_advect_tracers(ncrms, nx, nz, nt, *args)
+        rc = getattr(lib(), "mpdata_oracle_advect_tracers" + sfx)(ncrms, nx, nz, nt, *args)
     if rc != 0:
         raise RuntimeError(f"mpdata_oracle_advect failed rc={rc}")
     return f, flux
@@ -156,8 +178,9 @@ def max_threads():
 
 
 # ---------------------------------------------------------------- reference
-def ref_exe(ncrms, nx, nz):
-    p = os.path.join(REF_DIR, f"advect_ref_{ncrms}x{nx}x{nz}")
+def ref_exe(ncrms, nx, nz, dtype=np.float64):
+    sfx = "" if np.dtype(dtype) == np.float64 else "_f32"
+    p = os.path.join(REF_DIR, f"advect_ref_{ncrms}x{nx}x{nz}{sfx}")
     return p if os.path.exists(p) else None
 
 
@@ -172,7 +195,8 @@ def run_reference(inp, want_outputs=True):
     Returns (f_out, flux_out, cpu_timing_seconds)."""
     ncrms, nxp6, nzm = inp["f"].shape
     nx, nz = nxp6 - 6, nzm + 1
-    exe = ref_exe(ncrms, nx, nz)
+    dtype = inp["f"].dtype
+    exe = ref_exe(ncrms, nx, nz, dtype)
     if exe is None:
         raise FileNotFoundError(f"no oracle/_ref binary for shape {(ncrms, nx, nz)}")
     with tempfile.TemporaryDirectory(prefix="mpdata_refrun_") as tmp:
@@ -185,7 +209,7 @@ def run_reference(inp, want_outputs=True):
         timing = float(m.group(1)) if m else float("nan")
         if not want_outputs:
             return None, None, timing
-        raw = np.fromfile(os.path.join(tmp, "mpdata_out.bin"), dtype=np.float64)
+        raw = np.fromfile(os.path.join(tmp, "mpdata_out.bin"), dtype=dtype)
     nf = inp["f"].size
     f = raw[:nf].reshape(inp["f"].shape, order="F")
     flux = raw[nf:nf + inp["flux"].size].reshape(inp["flux"].shape, order="F")
@@ -194,4 +218,5 @@ def run_reference(inp, want_outputs=True):
 
 def rel_l1(a, b):
     """The reference's own metric (reference :681-682): sum|a-b| / sum|b|."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.sum(np.abs(a - b)) / np.sum(np.abs(b)))

@@ -37,8 +37,18 @@ CASES = [
 ]
 
 
-def case_name(ncrms, nx, nz, seed, dist):
-    return f"ref_{ncrms}x{nx}x{nz}_seed{seed}_dist{dist}"
+# fp32 build of the reference (rp = IEEE single; see oracle/build_ref.py, edit 4): pins the
+# fp32 build of the oracle (mpdata_oracle.c with -DMPDATA_ORACLE_F32)
+CASES_F32 = [
+    (3, 8, 6, 100, O.DIST_CONDITIONED),
+    (3, 8, 6, 100, O.DIST_RAW_SIGNED),
+    (8, 32, 28, 100, O.DIST_CONDITIONED),
+    (64, 32, 28, 100, O.DIST_RAW),
+]
+
+
+def case_name(ncrms, nx, nz, seed, dist, f32=False):
+    return f"ref_{ncrms}x{nx}x{nz}_seed{seed}_dist{dist}" + ("_f32" if f32 else "")
 
 
 def main():
@@ -47,15 +57,17 @@ def main():
                              "(advect_scalar2D_cpu, :477-642)",
                 "compiler": "amdflang -O3 -ffp-contract=off",
                 "cases": []}
-    for (ncrms, nx, nz, seed, dist) in CASES:
-        build_ref.build(ncrms, nx, nz)
-        inp = O.make_inputs(ncrms, nx, nz, seed=seed, dist=dist)
+    for (ncrms, nx, nz, seed, dist, f32) in [c + (False,) for c in CASES] + [c + (True,) for c in CASES_F32]:
+        build_ref.build(ncrms, nx, nz, f32=f32)
+        inp = O.make_inputs(ncrms, nx, nz, seed=seed, dist=dist,
+                            dtype=np.float32 if f32 else np.float64)
         f, flux, _ = O.run_reference(inp)
-        name = case_name(ncrms, nx, nz, seed, dist)
+        name = case_name(ncrms, nx, nz, seed, dist, f32)
         path = os.path.join(HERE, name + ".npz")
         np.savez(path, f=f, flux=flux)
         manifest["cases"].append({
             "name": name, "ncrms": ncrms, "nx": nx, "nz": nz, "seed": seed, "dist": dist,
+            "dtype": "f32" if f32 else "f64",
             "f_sha256": hashlib.sha256(f.tobytes(order="F")).hexdigest(),
             "flux_sha256": hashlib.sha256(flux.tobytes(order="F")).hexdigest(),
             "inputs_sha256": hashlib.sha256(b"".join(

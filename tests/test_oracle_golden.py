@@ -23,6 +23,27 @@ def test_oracle_matches_reference_golden_bitwise(oracle, case):
     assert np.array_equal(flux, flux_ref)  # includes the untouched level nz
 
 
+@pytest.mark.parametrize("case", golden_cases("f32"), ids=lambda c: c["name"])
+def test_fp32_oracle_matches_fp32_reference_golden_bitwise(oracle, case):
+    """The fp32 build of the oracle against the fp32 build of the reference (rp = IEEE
+    single, reference :12-13)."""
+    inp = oracle.make_inputs(case["ncrms"], case["nx"], case["nz"], seed=case["seed"],
+                             dist=case["dist"], dtype=np.float32)
+    h = hashlib.sha256(b"".join(inp[k].tobytes(order="F")
+                                for k in ("adz", "f", "u", "w", "rho", "rhow", "flux"))).hexdigest()
+    assert h == case["inputs_sha256"]
+    f_ref, flux_ref = load_golden(case)
+    assert f_ref.dtype == np.float32
+    f, flux = oracle.advect(inp)
+    assert f.dtype == np.float32
+    assert np.array_equal(f, f_ref) and np.array_equal(flux, flux_ref)
+    # and the fp64 result rounds to within fp32 rounding noise of it (conditioned law only)
+    if case["dist"] == 1:
+        inp64 = {k: v.astype(np.float64) for k, v in inp.items()}
+        f64, _ = oracle.advect({k: np.asfortranarray(v) for k, v in inp64.items()})
+        assert np.max(np.abs(f64 - f)) < 2e-5
+
+
 @pytest.mark.parametrize("case", golden_cases()[:5], ids=lambda c: c["name"])
 def test_reference_binary_still_agrees(oracle, case):
     """When oracle/_ref holds the reference executable for a shape, run it."""
@@ -41,6 +62,9 @@ def test_generators_agree_bitwise(oracle):
             a = oracle.fill_array(name, shape, 1234, dist)
             b = oracle.fill_array_c(name, shape, 1234, dist)
             assert np.array_equal(a, b), (name, dist)
+            a32 = oracle.fill_array(name, shape, 1234, dist, dtype=np.float32)
+            b32 = oracle.fill_array_c(name, shape, 1234, dist, dtype=np.float32)
+            assert np.array_equal(a32, b32) and np.array_equal(a32, a.astype(np.float32))
     # value ranges of the conditioned law (SURVEY.md 8d "D1")
     inp = oracle.make_inputs(16, 8, 6, seed=3, dist=oracle.DIST_CONDITIONED)
     assert 0 <= inp["f"].min() and inp["f"].max() < 1

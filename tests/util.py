@@ -7,9 +7,10 @@ import numpy as np
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def golden_cases():
+def golden_cases(dtype="f64"):
+    """Fixtures of one precision ("f64": the reference as shipped; "f32": its fp32 build)."""
     with open(os.path.join(GOLDEN_DIR, "manifest.json")) as fh:
-        return json.load(fh)["cases"]
+        return [c for c in json.load(fh)["cases"] if c.get("dtype", "f64") == dtype]
 
 
 def load_golden(case):
