@@ -171,7 +171,8 @@ struct TileV2 {
   static constexpr int THREADS = 64 * NWV;     // = 16 * LPS
   static constexpr int RS = G_ + 1;           // out tile: LDS row stride in doubles
   static constexpr int NZM_MAX = LPS - 1;
-  static constexpr int NSLOT = 4;              // input ring: columns q .. q+3
+  static constexpr int NSLOT = 4;              // input ring: columns q .. q+3 (a 5-slot ring,
+                                               // one more column in flight, measured 1.5 % slower)
   static constexpr int ARR = LPS * G_;         // doubles of one array block (LPS rows x G)
   static constexpr int IN_SLOT = 3 * ARR + G_; // f,u,w rows of one column + one row of zeros
   static constexpr int OUT_SLOT = NZM_MAX * RS;
@@ -304,6 +305,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   // all DMA of column `col` into its ring slot (6 instructions per wave)
   auto dma_col = [&](const int col) __attribute__((always_inline)) {
+#ifdef MPD2_ABL_NODMA  // timing ablation only: the arithmetic on whatever the LDS ring holds
+    return;
+#endif
     const unsigned cf = colb * (unsigned)(min(max(col, -2), nx + 3) + 2);
     const unsigned cu = colb * (unsigned)(min(max(col, -1), nx + 3) + 1);
     const unsigned cw = colb * (unsigned)(min(max(col, -1), nx + 2) + 1);
@@ -359,21 +363,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     // column q landed (this wave's DMA of it is 2 steps = 14 vector-memory ops
     // old), out tile of column q-4 written: then everyone's are, after the barrier
     STAMP();
+    static_assert(T::NSLOT == 4 && T::VM_PER_STEP == 7, "the counted wait below assumes them");
     asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
     STAMP();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     STAMP();
 
-    // ---- write back the column finished in the previous step (n = q-4); an
-    //      inactive step stores out of range (dropped), the op count stays fixed
-    {
-      const bool act = q - 4 >= -1 && q - 4 <= nx + 2;
-      st_row(rsf, (FULL || act) ? tf : OOB, colb * (unsigned)max(q - 4 + 2, 0),
-             out_slot0[((q - 1) & 1) * T::OUT_SLOT + t_lds]);
-    }
-    // ---- column q+3 into flight -------------------------------------------------
-    dma_col(q + 3);
 
     // ---- this column, transposed: lanes along k -------------------------------
     const double* s = in_slot0 + (q & (T::NSLOT - 1)) * T::IN_SLOT;
@@ -539,6 +535,19 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     S.U3[C2] = U3_2;
     S.DW3[C2] = DW3_2;
 
+    // ---- the step's vector-memory instructions, at its END: a wave that the saturated
+    //      memory pipeline holds up at issue would be waiting for the barrier here anyway
+    //      (issued at the start of the step they delayed its arithmetic: 2 % slower).
+    //      Write back the column finished in the previous step (n = q-4; an inactive step
+    //      stores out of range -- dropped -- so the op count stays fixed), then column q+3
+    //      into flight (its ring slot held column q-1, last read before this step's barrier).
+    asm volatile("" ::: "memory");
+    {
+      const bool act = q - 4 >= -1 && q - 4 <= nx + 2;
+      st_row(rsf, (FULL || act) ? tf : OOB, colb * (unsigned)max(q - 4 + 2, 0),
+             out_slot0[((q - 1) & 1) * T::OUT_SLOT + t_lds]);
+    }
+    dma_col(q + T::NSLOT - 1);
   };
 
 #undef DN_C
@@ -559,7 +568,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   // columns -2, -1, 0 into flight, each behind a dropped store so that the
   // counted wait of the first steps sees the steady-state op pattern
 #pragma unroll
-  for (int c = q_first; c < q_first + 3; ++c) {
+  for (int c = q_first; c < q_first + T::NSLOT - 1; ++c) {
     st_row(rsf, OOB, 0, 0.0);
     dma_col(c);
   }

@@ -1,0 +1,41 @@
+// Diagnostic: practical HBM streaming rates of this GPU for linear (perfectly coalesced,
+// 16 B per lane) access: read-only, copy (1R:1W) and the kernel's mix (3R:1W).
+// Arrays of 538 MB each (the size of f at ncrms=65536, nx=32, nz=28).  Not part of the product.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef double d2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) k_read(const d2* a, const d2* b, const d2* c, d2* o, size_t n) {
+  d2 acc = {0, 0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += a[i] + b[i] + c[i];
+  if (acc.x == 1.2345e300) o[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_copy(const d2* a, d2* o, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = a[i];
+}
+__global__ void __launch_bounds__(256) k_mix(const d2* a, const d2* b, const d2* c, d2* o, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = a[i] + b[i] + c[i];
+}
+int main() {
+  const size_t bytes = 65536ull * 38 * 27 * 8, n = bytes / 16;
+  d2 *a, *b, *c, *o;
+  (void)hipMalloc(&a, bytes); (void)hipMalloc(&b, bytes); (void)hipMalloc(&c, bytes); (void)hipMalloc(&o, bytes);
+  (void)hipMemset(a, 0, bytes); (void)hipMemset(b, 0, bytes); (void)hipMemset(c, 0, bytes); (void)hipMemset(o, 0, bytes);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int grid : {2048, 8192, 65536}) {
+    for (int which = 0; which < 3; ++which) {
+      float best = 1e9f;
+      for (int r = 0; r < 6; ++r) {
+        (void)hipEventRecord(e0);
+        if (which == 0) hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, a, b, c, o, n);
+        if (which == 1) hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, a, o, n);
+        if (which == 2) hipLaunchKernelGGL(k_mix, dim3(grid), dim3(256), 0, 0, a, b, c, o, n);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && ms < best) best = ms;
+      }
+      const double moved = (double)bytes * (which == 0 ? 3 : which == 1 ? 2 : 4);
+      printf("grid %6d %-10s %.3f ms  %.2f TB/s\n", grid, which == 0 ? "read 3R" : which == 1 ? "copy 1R:1W" : "mix 3R:1W", best, moved / (best * 1e-3) / 1e12);
+    }
+  }
+  return 0;
+}
