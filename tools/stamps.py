@@ -44,3 +44,13 @@ print("stage A by step:   ", " ".join("%d" % x for x in np.median(a, axis=0)))
 print("stage B-D by step: ", " ".join("%d" % x for x in np.median(rest, axis=0)))
 r0s = (s[:, 1] - s[:, 1].min()) / 100.0
 print("WG start times us: p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(r0s, [10, 50, 90, 100])))
+# occupancy of the 512 workgroup slots (256 CUs x 2) over the kernel's life
+t_s = (s[:, 1] - s[:, 1].min()) / 100.0
+t_e = (s[:, 3] - s[:, 1].min()) / 100.0
+edges = np.arange(0, t_e.max() + 20, 20.0)
+occ = [int(((t_s < b) & (t_e > a)).sum()) for a, b in zip(edges[:-1], edges[1:])]
+print("workgroups alive per 20-us window:", " ".join(str(x) for x in occ))
+print("sum of lifetimes / (span x 512 slots) = %.3f" % ((t_e - t_s).sum() / (t_e.max() * 512)))
+order = np.argsort(t_s)
+life = (t_e - t_s)[order]
+print("lifetime by start order (mean of each 512): ", " ".join("%.1f" % life[i:i + 512].mean() for i in range(0, nblk, 512)))
