@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--variant", choices=["exact", "fast"], default=os.environ.get("MPDATA_VARIANT", "fast"),
                     help="fast: FMA contraction (max|df| < 1e-12 vs the reference, tests/test_hip_parity.py); "
                          "exact: bit-identical f")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="f64: the headline (BASELINE.json fp64); f32: the reference's precision switch")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 side measurement")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--dist", type=int, default=1, help="1 conditioned, 2 reference-raw, 3 raw-signed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -98,14 +101,15 @@ def cpu_baseline(nx, nz):
     return out
 
 
-def make_problem(M, torch, dev, ncrms_loc, ncrms_glob, sl0, nx, nz, ntr, nbuf, dist):
+def make_problem(M, torch, dev, ncrms_loc, ncrms_glob, sl0, nx, nz, ntr, nbuf, dist, dtype=None):
+    dtype = torch.float64 if dtype is None else dtype
     sh = M.shapes(ncrms_loc, nx, nz, ntr)
-    d = {k: torch.empty(sh[k], dtype=torch.float64, device=dev) for k in ("u", "w", "rho", "rhow", "adz", "flux")}
+    d = {k: torch.empty(sh[k], dtype=dtype, device=dev) for k in ("u", "w", "rho", "rhow", "adz", "flux")}
     for k in d:
         M.fill_synthetic(d[k], k, 100, dist, ncrms_global=ncrms_glob, sl0=sl0)
     fs = []
     for b in range(nbuf):
-        f = torch.empty(sh["f"], dtype=torch.float64, device=dev)
+        f = torch.empty(sh["f"], dtype=dtype, device=dev)
         # per-tracer / per-buffer seeds: distinct data, same law
         if ntr == 1:
             M.fill_synthetic(f, "f", 100 + b, dist, ncrms_global=ncrms_glob, sl0=sl0)
@@ -176,11 +180,13 @@ def main():
 
     # ---- headline: 1 tracer (or --tracers) ---------------------------------
     ntr = args.tracers
-    d, fs = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, ntr, steps + warmup, args.dist)
+    f32 = args.dtype == "f32"
+    tdt = torch.float32 if f32 else torch.float64
+    d, fs = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, ntr, steps + warmup, args.dist, tdt)
     dt, kms = timed_run(M, torch, dist, world, d, fs, steps, warmup)
     cells_per_step = n_glob * nx * (nz - 1) * ntr
     value = cells_per_step * steps / dt
-    alg_bytes = M.algorithmic_bytes(n_loc, nx, nz, ntr)  # per launch (one GPU)
+    alg_bytes = M.algorithmic_bytes(n_loc, nx, nz, ntr, f32=f32)  # per launch (one GPU)
     k_avg = sum(kms) / len(kms)
     achieved = alg_bytes / (k_avg * 1e-3) / 1e9
     del fs
@@ -193,7 +199,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t{ntr}"
+                key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t{ntr}" + ("_f32" if f32 else "")
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -201,9 +207,10 @@ def main():
             "metric": "advected cell-updates/sec, MPDATA advect_scalar2D (ncrms=65536 per GPU, nx=32, nz=28)",
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[2]: ncrms={n_loc}/GPU (global {n_glob}) nx={nx} "
-                                   f"nz={nz} fp64 tracers={ntr}, device-resident, in-place f",
+                                   f"nz={nz} {'fp32 (NOT the headline precision)' if f32 else 'fp64'} "
+                                   f"tracers={ntr}, device-resident, in-place f",
                        "ncrms_per_gpu": n_loc, "ncrms_global": n_glob, "nx": nx, "nz": nz,
                        "ntracers": ntr, "variant": args.variant, "input_law": args.dist,
                        "parallelism": f"ncrms-sharded x{world}, no data-path collective"},
@@ -219,10 +226,10 @@ def main():
     if not args.no_batched and ntr == 1:
         bt = args.batched_tracers
         bsteps, bwarm = min(steps, 5), 1
-        d2, fs2 = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, bt, bsteps + bwarm, args.dist)
+        d2, fs2 = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, bt, bsteps + bwarm, args.dist, tdt)
         dt2, kms2 = timed_run(M, torch, dist, world, d2, fs2, bsteps, bwarm)
         if rank == 0:
-            ab = M.algorithmic_bytes(n_loc, nx, nz, bt)
+            ab = M.algorithmic_bytes(n_loc, nx, nz, bt, f32=f32)
             ka = sum(kms2) / len(kms2)
             result["tracer_batched"] = {
                 "workload": f"BASELINE.json configs[3]: ncrms={n_loc}/GPU, {bt} tracers sharing u,w,rho,rhow,adz",
@@ -232,6 +239,23 @@ def main():
                              "unit": "GB/s", "frac": ab / (ka * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": ab, "kernel_ms_avg": ka}}
         del fs2, d2
+        torch.cuda.empty_cache()
+
+    # ---- side measurement: the same workload in fp32 (reference precision switch) ------
+    if not args.no_fp32 and not f32 and ntr == 1:
+        d3, fs3 = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, 1, steps + warmup, args.dist, torch.float32)
+        dt3, kms3 = timed_run(M, torch, dist, world, d3, fs3, steps, warmup)
+        if rank == 0:
+            ab = M.algorithmic_bytes(n_loc, nx, nz, 1, f32=True)
+            ka = sum(kms3) / len(kms3)
+            result["fp32"] = {
+                "workload": f"ncrms={n_loc}/GPU nx={nx} nz={nz} fp32, 1 tracer (mpdata_advect_scalar2d_f32_device)",
+                "value": n_glob * nx * (nz - 1) * steps / dt3, "unit": "cell-updates/s", "steps": steps,
+                "ms_per_step": dt3 / steps * 1e3,
+                "roofline": {"bound": "hbm", "achieved": ab / (ka * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": ab / (ka * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": ab, "kernel_ms_avg": ka}}
+        del fs3, d3
         torch.cuda.empty_cache()
 
     # ---- optional: scatter/gather over RCCL (outside any timed region) ------

@@ -76,6 +76,14 @@ def lib():
         L.mpdata_pack_shard_device.argtypes = [dp, dp, i64, i64, i64, i64, vp]
         L.mpdata_unpack_shard_device.restype = ci
         L.mpdata_unpack_shard_device.argtypes = [dp, dp, i64, i64, i64, i64, vp]
+        L.mpdata_advect_scalar2d_f32.restype = ci
+        L.mpdata_advect_scalar2d_f32.argtypes = [i64, ci, ci, ci] + [dp] * 7
+        L.mpdata_advect_scalar2d_f32_device.restype = ci
+        L.mpdata_advect_scalar2d_f32_device.argtypes = [i64, ci, ci, ci] + [dp] * 7 + [vp]
+        L.mpdata_fill_synthetic_f32_device.restype = ci
+        L.mpdata_fill_synthetic_f32_device.argtypes = [dp, ci, i64, i64, i64, i64, ctypes.c_uint64, ci, vp]
+        L.mpdata_algorithmic_bytes_f32.restype = i64
+        L.mpdata_algorithmic_bytes_f32.argtypes = [i64, ci, ci, ci]
         L.mpdata_set_variant.restype = ci
         L.mpdata_set_variant.argtypes = [ci]
         L.mpdata_get_variant.restype = ci
@@ -113,8 +121,9 @@ def device_count():
     return lib().mpdata_device_count()
 
 
-def algorithmic_bytes(ncrms, nx, nz, ntracers=1):
-    return int(lib().mpdata_algorithmic_bytes(ncrms, nx, nz, ntracers))
+def algorithmic_bytes(ncrms, nx, nz, ntracers=1, f32=False):
+    fn = lib().mpdata_algorithmic_bytes_f32 if f32 else lib().mpdata_algorithmic_bytes
+    return int(fn(ncrms, nx, nz, ntracers))
 
 
 SID = {"adz": 0, "f": 1, "u": 2, "w": 3, "rho": 4, "rhow": 5, "flux": 6}
@@ -144,10 +153,11 @@ def _dims_from(f, u):
     return ncrms, nxp6 - 6, nzm + 1, nt
 
 
-def _dev_ptr(t, shape, name):
+def _dev_ptr(t, shape, name, dtype=None):
     import torch
-    if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
-        raise MpdataError(-1, f"{name}: need a contiguous float64 device tensor")
+    dtype = torch.float64 if dtype is None else dtype
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise MpdataError(-1, f"{name}: need a contiguous {dtype} device tensor")
     if tuple(t.shape) != tuple(shape):
         raise MpdataError(-1, f"{name}: shape {tuple(t.shape)} != expected {tuple(shape)}")
     return ctypes.c_void_p(t.data_ptr())
@@ -156,18 +166,23 @@ def _dev_ptr(t, shape, name):
 def advect_scalar2D(f, u, w, rho, rhow, flux, adz, stream=None):
     """Device-resident `call advect_scalar2D(f,u,w,rho,rhow,flux)` (reference
     :53/:57; adz is host-associated there, :30).  torch float64 device tensors
-    in the reversed-axes layout; f and flux are updated in place; asynchronous
-    on `stream` (default: torch's current stream)."""
+    (or float32, all seven: the reference's `rp` switch, :12-13) in the
+    reversed-axes layout; f and flux are updated in place; asynchronous on
+    `stream` (default: torch's current stream)."""
+    import torch
     ncrms, nx, nz, nt = _dims_from(f, u)
     sh = shapes(ncrms, nx, nz, nt)
-    ptrs = [_dev_ptr(t, sh[k], k) for k, t in
+    if f.dtype not in (torch.float64, torch.float32):
+        raise MpdataError(-1, f"f: dtype {f.dtype} is neither float64 nor float32")
+    ptrs = [_dev_ptr(t, sh[k], k, f.dtype) for k, t in
             (("f", f), ("u", u), ("w", w), ("rho", rho), ("rhow", rhow), ("adz", adz), ("flux", flux))]
-    _check(lib().mpdata_advect_scalar2d_device(ncrms, nx, nz, nt, *ptrs, _stream_handle(stream)))
+    fn = lib().mpdata_advect_scalar2d_device if f.dtype == torch.float64 else lib().mpdata_advect_scalar2d_f32_device
+    _check(fn(ncrms, nx, nz, nt, *ptrs, _stream_handle(stream)))
 
 
-def _host_ptr(a, name, writable=False):
-    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["F_CONTIGUOUS"]):
-        raise MpdataError(-1, f"{name}: need a Fortran-ordered float64 numpy array")
+def _host_ptr(a, name, writable=False, dtype=np.float64):
+    if not (isinstance(a, np.ndarray) and a.dtype == dtype and a.flags["F_CONTIGUOUS"]):
+        raise MpdataError(-1, f"{name}: need a Fortran-ordered {np.dtype(dtype).name} numpy array")
     if writable and not a.flags["WRITEABLE"]:
         raise MpdataError(-1, f"{name}: not writable")
     return ctypes.c_void_p(a.ctypes.data)
@@ -184,10 +199,13 @@ def advect_scalar2D_host(f, u, w, rho, rhow, flux, adz):
     reference shapes): H2D + kernel + D2H, like the reference's OpenACC
     routine with its update device/host directives (:107, :241)."""
     ncrms, nx, nz, nt = _host_dims(f)
-    _check(lib().mpdata_advect_scalar2d(
-        ncrms, nx, nz, nt, _host_ptr(f, "f", True), _host_ptr(u, "u"), _host_ptr(w, "w"),
-        _host_ptr(rho, "rho"), _host_ptr(rhow, "rhow"), _host_ptr(adz, "adz"),
-        _host_ptr(flux, "flux", True)))
+    dt = np.float32 if isinstance(f, np.ndarray) and f.dtype == np.float32 else np.float64
+    fn = lib().mpdata_advect_scalar2d if dt == np.float64 else lib().mpdata_advect_scalar2d_f32
+    _check(fn(
+        ncrms, nx, nz, nt, _host_ptr(f, "f", True, dt), _host_ptr(u, "u", False, dt),
+        _host_ptr(w, "w", False, dt), _host_ptr(rho, "rho", False, dt),
+        _host_ptr(rhow, "rhow", False, dt), _host_ptr(adz, "adz", False, dt),
+        _host_ptr(flux, "flux", True, dt)))
 
 
 class Plan:
@@ -236,9 +254,13 @@ def fill_synthetic(t, name, seed, dist, ncrms_global=None, sl0=0, stream=None):
     instances) with the synthetic law of array `name`."""
     nloc = t.shape[-1]
     rows = t.numel() // nloc
+    import torch
     ng = nloc if ncrms_global is None else ncrms_global
-    _check(lib().mpdata_fill_synthetic_device(ctypes.c_void_p(t.data_ptr()), SID[name], rows, ng,
-                                              sl0, nloc, seed, dist, _stream_handle(stream)))
+    fn = lib().mpdata_fill_synthetic_device if t.dtype == torch.float64 else lib().mpdata_fill_synthetic_f32_device
+    if t.dtype not in (torch.float64, torch.float32) or not t.is_contiguous():
+        raise MpdataError(-1, f"{name}: need a contiguous float64 or float32 device tensor")
+    _check(fn(ctypes.c_void_p(t.data_ptr()), SID[name], rows, ng, sl0, nloc, seed, dist,
+              _stream_handle(stream)))
 
 
 def pack_shard(full, sl0, nloc, out=None, stream=None):

@@ -5,20 +5,24 @@
 // Arrays are the reference's dummy arguments (reference
 // mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:479-484) plus the
 // host-associated adz (:30); see include/mpdata_hip.h for the layout.
-struct MpdataArgs {
-  double* f;
-  const double* u;
-  const double* w;
-  const double* rho;
-  const double* rhow;
-  const double* adz;
-  double* flux;
+// R = double (the reference as shipped, :13) or float (its fp32 build, :12).
+template <typename R>
+struct MpdataArgsT {
+  R* f;
+  const R* u;
+  const R* w;
+  const R* rho;
+  const R* rhow;
+  const R* adz;
+  R* flux;
   long long ncrms;         // CRM instances = leading dimension of every array
   int nx, nz;
   long long f_tstride;     // elements between consecutive tracers of f
   long long flux_tstride;  // ... of flux
   unsigned long long* dbg;  // diagnostic builds only (-DMPD2_STAMPS): in-kernel clock stamps; else null
 };
+typedef MpdataArgsT<double> MpdataArgs;
+typedef MpdataArgsT<float> MpdataArgsF32;
 
 // One tiling of the kernel template (W columns per thread, SPW strips per
 // wave, NWV waves per workgroup).
@@ -28,6 +32,7 @@ struct MpdataTileInfo {
   int slw;      // CRM instances per workgroup
   int ncol;     // columns covered (needs nx + 4 <= ncol); k-marching kernels only
   int nz_max;   // largest nz; x-marching kernels only (lanes along k)
+  int elem_bytes;  // 8: fp64 kernels, 4: fp32 kernels
   int threads;
   const char* name;
 };

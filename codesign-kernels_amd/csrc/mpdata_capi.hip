@@ -18,11 +18,13 @@ namespace mpdata_exact {
 int max_tile_id();
 bool tile_info(int id, MpdataTileInfo* info);
 bool launch(int id, const MpdataArgs& a, int ntracers, void* stream);
+bool launch_f32(int id, const MpdataArgsF32& a, int ntracers, void* stream);
 }  // namespace mpdata_exact
 namespace mpdata_fast {
 int max_tile_id();
 bool tile_info(int id, MpdataTileInfo* info);
 bool launch(int id, const MpdataArgs& a, int ntracers, void* stream);
+bool launch_f32(int id, const MpdataArgsF32& a, int ntracers, void* stream);
 }  // namespace mpdata_fast
 
 namespace {
@@ -73,13 +75,18 @@ bool get_tile(int var, int id, MpdataTileInfo* t) {
 // Automatic choice: the x-marching kernel with the fewest lanes per instance
 // that holds nz (lanes along k, any nx); if nz is too large for one wave, the
 // k-marching kernel with the smallest column coverage that fits nx.
-int choose_tile(int var, int64_t ncrms, int nx, int nz, MpdataTileInfo* out) {
+// fp32 (elem_bytes = 4): the two-instances-per-lane kernels (tile ids >= 40) when ncrms is
+// even, else the one-instance-per-lane ones (nz <= 32).
+int choose_tile(int var, int64_t ncrms, int nx, int nz, MpdataTileInfo* out, int elem_bytes = 8) {
   // the x-marching kernels address rows with 32-bit byte offsets inside one array
-  const bool small32 = (double)ncrms * (nx + 6) * nz * 8.0 < 4294967296.0;
-  const int forced = tile_override();
+  const bool small32 = (double)ncrms * (nx + 6) * nz * (double)elem_bytes < 4294967296.0;
+  int forced = tile_override();
   MpdataTileInfo t;
+  if (forced >= 0 && get_tile(var, forced, &t) && t.elem_bytes != elem_bytes) forced = -1;  // other precision
   if (forced >= 0) {
     if (!get_tile(var, forced, &t)) return set_err(MPDATA_EINVAL, "unknown tile id %d", forced);
+    if (t.id >= 40 && (ncrms & 1))
+      return set_err(MPDATA_EUNSUPPORTED, "tile %s needs an even ncrms", t.name);
     if (t.ncol < nx + 4 || t.nz_max < nz || (t.nz_max < (1 << 30) && !small32))
       return set_err(MPDATA_EUNSUPPORTED, "tile %s covers %d columns / nz<=%d; nx=%d nz=%d", t.name,
                      t.ncol, t.nz_max, nx, nz);
@@ -90,15 +97,20 @@ int choose_tile(int var, int64_t ncrms, int nx, int nz, MpdataTileInfo* out) {
   const int n = (var == MPDATA_VARIANT_FAST ? mpdata_fast::max_tile_id() : mpdata_exact::max_tile_id()) + 1;
   for (int id = 0; id < n; ++id) {
     if (!get_tile(var, id, &t)) continue;
+    if (t.elem_bytes != elem_bytes) continue;
+    if (t.id >= 40 && (ncrms & 1)) continue;
     if (t.ncol < nx + 4 || t.nz_max < nz) continue;
     if (t.nz_max < (1 << 30) && !small32) continue;
     // x-marching tiles (finite nz_max) first, by lanes per instance; then k-marching by columns
     // (among x-marching tiles of equal lanes-per-instance the smaller workgroup is the default)
-    const int cost = t.nz_max < (1 << 30) ? t.nz_max * 100 + t.slw : 100000 + t.ncol;
+    const int cost = t.nz_max < (1 << 30) ? t.nz_max * 100 + t.slw - (t.id >= 40 ? 50 : 0) : 100000 + t.ncol;
     if (cost < best_cost) { best = id; best_cost = cost; }
   }
   if (best < 0)
-    return set_err(MPDATA_EUNSUPPORTED, "no kernel tiling covers nx=%d nz=%d (need nz<=64 or nx<=140)", nx, nz);
+    return set_err(MPDATA_EUNSUPPORTED,
+                   elem_bytes == 8 ? "no kernel tiling covers nx=%d nz=%d (need nz<=64 or nx<=140)"
+                                   : "no fp32 kernel tiling covers nx=%d nz=%d (need nz<=64, and nz<=32 for odd ncrms)",
+                   nx, nz);
   get_tile(var, best, out);
   return 0;
 }
@@ -135,7 +147,8 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-__global__ void fill_kernel(double* a, unsigned long long base, double shift, long long rows,
+template <typename R>
+__global__ void fill_kernel(R* a, unsigned long long base, double shift, long long rows,
                             long long ng, long long sl0, long long nloc) {
   const long long total = rows * nloc;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -143,7 +156,7 @@ __global__ void fill_kernel(double* a, unsigned long long base, double shift, lo
     const long long r = t / nloc, s = t - r * nloc;
     const unsigned long long j = (unsigned long long)(r * ng + sl0 + s);
     const unsigned long long z = mix64(base + (j + 1) * 0x9E3779B97F4A7C15ull);
-    a[t] = __dadd_rn((double)(z >> 11) * 0x1.0p-53, shift);
+    a[t] = (R)__dadd_rn((double)(z >> 11) * 0x1.0p-53, shift);  // fp32: the fp64 value, rounded
   }
 }
 
@@ -165,6 +178,56 @@ unsigned grid_for(long long total, int block) {
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+template <typename R>
+int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u, const R* w,
+                  const R* rho, const R* rhow, const R* adz, R* flux, void* stream) {
+  int rc = validate(ncrms, nx, nz, ntracers);
+  if (rc) return rc;
+  if (!f || !u || !w || !rho || !rhow || !adz || !flux)
+    return set_err(MPDATA_EINVAL, "null array pointer");
+  const int var = variant();
+  MpdataTileInfo t;
+  rc = choose_tile(var, ncrms, nx, nz, &t, (int)sizeof(R));
+  if (rc) return rc;
+  MpdataArgsT<R> a;
+  a.f = f; a.u = u; a.w = w; a.rho = rho; a.rhow = rhow; a.adz = adz; a.flux = flux;
+  a.ncrms = ncrms; a.nx = nx; a.nz = nz;
+  a.f_tstride = (long long)ncrms * (nx + 6) * (nz - 1);
+  a.flux_tstride = (long long)ncrms * nz;
+  a.dbg = g_dbg;
+  bool ok;
+  if constexpr (sizeof(R) == 8)
+    ok = var == MPDATA_VARIANT_FAST ? mpdata_fast::launch(t.id, a, ntracers, stream)
+                                    : mpdata_exact::launch(t.id, a, ntracers, stream);
+  else
+    ok = var == MPDATA_VARIANT_FAST ? mpdata_fast::launch_f32(t.id, a, ntracers, stream)
+                                    : mpdata_exact::launch_f32(t.id, a, ntracers, stream);
+  if (!ok) return set_err(MPDATA_EINVAL, "tile %d not instantiated", t.id);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <typename R>
+int fill_device(R* a, int sid, int64_t rows, int64_t ncrms_global, int64_t sl0, int64_t nloc,
+                uint64_t seed, int dist, void* stream) {
+  if (!a || sid < 0 || sid > 6 || rows < 1 || nloc < 1 || sl0 < 0 || sl0 + nloc > ncrms_global ||
+      dist < 1 || dist > 3)
+    return set_err(MPDATA_EINVAL, "bad argument to mpdata_fill_synthetic_device");
+  double shift = 0.0;
+  if (dist == 1) {
+    if (sid == 2 || sid == 3) shift = -0.5;
+    else if (sid == 0 || sid == 4 || sid == 5) shift = 0.5;
+  } else if (dist == 3) {
+    if (sid == 2 || sid == 3) shift = -0.5;
+  }
+  const unsigned long long base = seed + (unsigned long long)sid * 0xD1B54A32D192ED03ull;
+  hipLaunchKernelGGL(fill_kernel<R>, dim3(grid_for(rows * nloc, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a, base, shift, (long long)rows, (long long)ncrms_global,
+                     (long long)sl0, (long long)nloc);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 }  // namespace
 
 struct mpdata_plan {
@@ -183,25 +246,14 @@ int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers, d
                                   const double* u, const double* w, const double* rho,
                                   const double* rhow, const double* adz, double* flux,
                                   void* stream) {
-  int rc = validate(ncrms, nx, nz, ntracers);
-  if (rc) return rc;
-  if (!f || !u || !w || !rho || !rhow || !adz || !flux)
-    return set_err(MPDATA_EINVAL, "null array pointer");
-  const int var = variant();
-  MpdataTileInfo t;
-  rc = choose_tile(var, ncrms, nx, nz, &t);
-  if (rc) return rc;
-  MpdataArgs a;
-  a.f = f; a.u = u; a.w = w; a.rho = rho; a.rhow = rhow; a.adz = adz; a.flux = flux;
-  a.ncrms = ncrms; a.nx = nx; a.nz = nz;
-  a.f_tstride = (long long)ncrms * (nx + 6) * (nz - 1);
-  a.flux_tstride = (long long)ncrms * nz;
-  a.dbg = g_dbg;
-  const bool ok = var == MPDATA_VARIANT_FAST ? mpdata_fast::launch(t.id, a, ntracers, stream)
-                                             : mpdata_exact::launch(t.id, a, ntracers, stream);
-  if (!ok) return set_err(MPDATA_EINVAL, "tile %d not instantiated", t.id);
-  HIP_TRY(hipGetLastError());
-  return 0;
+  return advect_device<double>(ncrms, nx, nz, ntracers, f, u, w, rho, rhow, adz, flux, stream);
+}
+
+int mpdata_advect_scalar2d_f32_device(int64_t ncrms, int nx, int nz, int ntracers, float* f,
+                                      const float* u, const float* w, const float* rho,
+                                      const float* rhow, const float* adz, float* flux,
+                                      void* stream) {
+  return advect_device<float>(ncrms, nx, nz, ntracers, f, u, w, rho, rhow, adz, flux, stream);
 }
 
 int mpdata_plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan) {
@@ -411,21 +463,37 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
 int mpdata_fill_synthetic_device(double* a, int sid, int64_t rows, int64_t ncrms_global,
                                  int64_t sl0, int64_t nloc, uint64_t seed, int dist,
                                  void* stream) {
-  if (!a || sid < 0 || sid > 6 || rows < 1 || nloc < 1 || sl0 < 0 || sl0 + nloc > ncrms_global ||
-      dist < 1 || dist > 3)
-    return set_err(MPDATA_EINVAL, "bad argument to mpdata_fill_synthetic_device");
-  double shift = 0.0;
-  if (dist == 1) {
-    if (sid == 2 || sid == 3) shift = -0.5;
-    else if (sid == 0 || sid == 4 || sid == 5) shift = 0.5;
-  } else if (dist == 3) {
-    if (sid == 2 || sid == 3) shift = -0.5;
+  return fill_device<double>(a, sid, rows, ncrms_global, sl0, nloc, seed, dist, stream);
+}
+int mpdata_fill_synthetic_f32_device(float* a, int sid, int64_t rows, int64_t ncrms_global,
+                                     int64_t sl0, int64_t nloc, uint64_t seed, int dist,
+                                     void* stream) {
+  return fill_device<float>(a, sid, rows, ncrms_global, sl0, nloc, seed, dist, stream);
+}
+
+// fp32 host-array call: one piece (allocate, copy in, run, copy f and flux back).
+int mpdata_advect_scalar2d_f32(int64_t ncrms, int nx, int nz, int ntracers, float* f, const float* u,
+                               const float* w, const float* rho, const float* rhow,
+                               const float* adz, float* flux) {
+  int rc = validate(ncrms, nx, nz, ntracers);
+  if (rc) return rc;
+  if (!f || !u || !w || !rho || !rhow || !adz || !flux) return set_err(MPDATA_EINVAL, "null array pointer");
+  const Sizes sz = sizes_of(ncrms, nx, nz, ntracers);
+  const size_t n[7] = {sz.f, sz.u, sz.w, sz.k, sz.kz, sz.k, sz.kz * (size_t)ntracers};
+  const float* h[7] = {f, u, w, rho, rhow, adz, flux};
+  float* d[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 7 && e == hipSuccess; ++i) e = hipMalloc((void**)&d[i], n[i] * 4);
+  for (int i = 0; i < 7 && e == hipSuccess; ++i) e = hipMemcpy(d[i], h[i], n[i] * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = mpdata_advect_scalar2d_f32_device(ncrms, nx, nz, ntracers, d[0], d[1], d[2], d[3], d[4], d[5], d[6], nullptr);
+    if (rc == 0) e = hipMemcpy(f, d[0], n[0] * 4, hipMemcpyDeviceToHost);
+    if (rc == 0 && e == hipSuccess) e = hipMemcpy(flux, d[6], n[6] * 4, hipMemcpyDeviceToHost);
   }
-  const unsigned long long base = seed + (unsigned long long)sid * 0xD1B54A32D192ED03ull;
-  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(rows * nloc, 256)), dim3(256), 0,
-                     (hipStream_t)stream, a, base, shift, (long long)rows, (long long)ncrms_global,
-                     (long long)sl0, (long long)nloc);
-  HIP_TRY(hipGetLastError());
+  for (int i = 0; i < 7; ++i)
+    if (d[i]) (void)hipFree(d[i]);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_err(e, "mpdata_advect_scalar2d_f32");
   return 0;
 }
 
@@ -474,6 +542,9 @@ int mpdata_device_count(void) {
 int64_t mpdata_algorithmic_bytes(int64_t ncrms, int nx, int nz, int ntracers) {
   const int64_t nzm = nz - 1;
   return ncrms * 8 * nzm * ((int64_t)ntracers * (2 * nx + 11) + 2 * nx + 12);
+}
+int64_t mpdata_algorithmic_bytes_f32(int64_t ncrms, int nx, int nz, int ntracers) {
+  return mpdata_algorithmic_bytes(ncrms, nx, nz, ntracers) / 2;
 }
 const char* mpdata_last_error(void) { return g_err.c_str(); }
 const char* mpdata_version(void) { return "mpdata-hip 0.1 (gfx950)"; }

@@ -59,41 +59,70 @@ namespace MPDATA_NS {
 namespace v2 {
 
 
+// ---- real-type helpers.  R is the type a LANE computes in:
+//        double  the reference as shipped (:13);
+//        float   its fp32 build (:12), one instance per lane;
+//        f32x2   fp32, TWO adjacent instances per lane: the same 8 bytes per lane and element
+//                as the fp64 kernel (identical tiling, LDS image, DMA and stores), add / mul /
+//                fma as packed instructions (v_pk_*_f32); needs an even number of instances.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double dmax(double x, double y) { return __builtin_fmax(x, y); }
 __device__ __forceinline__ double dmin(double x, double y) { return __builtin_fmin(x, y); }
-// Statement functions of the reference (:500-503), left-to-right.
-__device__ __forceinline__ double andiff(double x1, double x2, double a, double b) {
-  return (__builtin_fabs(a) - a * a * b) * 0.5 * (x2 - x1);
+__device__ __forceinline__ float dmax(float x, float y) { return __builtin_fmaxf(x, y); }
+__device__ __forceinline__ float dmin(float x, float y) { return __builtin_fminf(x, y); }
+__device__ __forceinline__ f32x2 dmax(f32x2 x, f32x2 y) { return __builtin_elementwise_max(x, y); }
+__device__ __forceinline__ f32x2 dmin(f32x2 x, f32x2 y) { return __builtin_elementwise_min(x, y); }
+__device__ __forceinline__ double rabs(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float rabs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ f32x2 rabs(f32x2 x) { return __builtin_elementwise_abs(x); }
+__device__ __forceinline__ double rldexp(double x, int e) { return __builtin_ldexp(x, e); }
+__device__ __forceinline__ float rldexp(float x, int e) { return __builtin_ldexpf(x, e); }
+__device__ __forceinline__ f32x2 rldexp(f32x2 x, int e) { return f32x2{__builtin_ldexpf(x.x, e), __builtin_ldexpf(x.y, e)}; }
+// a >= 0 ? x : y per element
+__device__ __forceinline__ double sel_ge0(double a, double x, double y) { return a >= 0.0 ? x : y; }
+__device__ __forceinline__ float sel_ge0(float a, float x, float y) { return a >= 0.0f ? x : y; }
+__device__ __forceinline__ f32x2 sel_ge0(f32x2 a, f32x2 x, f32x2 y) {
+  return f32x2{a.x >= 0.0f ? x.x : y.x, a.y >= 0.0f ? x.y : y.y};
 }
-__device__ __forceinline__ double across(double x1, double a1, double a2) {
-  return 0.03125 * a1 * a2 * x1;
+// Statement functions of the reference (:500-503), left-to-right.
+template <typename R>
+__device__ __forceinline__ R andiff(R x1, R x2, R a, R b) {
+  return (rabs(a) - a * a * b) * R(0.5) * (x2 - x1);
+}
+template <typename R>
+__device__ __forceinline__ R across(R x1, R a1, R a2) {
+  return R(0.03125) * a1 * a2 * x1;
 }
 // max(0,a)*x + min(0,a)*y of the reference's upwind / limited fluxes (:532, :537, :618, :623).
 // One of the two products is an exact zero, so the value equals a * (a >= 0 ? x : y)
 // (the sign of a zero result aside); one select + one multiply instead of max, min, two
 // multiplies and an add.
-__device__ __forceinline__ double upwind(double a, double x, double y) { return a * (a >= 0.0 ? x : y); }
-__device__ __forceinline__ double pp(double y) { return dmax(0.0, y); }
-__device__ __forceinline__ double pn(double y) { return -dmin(0.0, y); }
+template <typename R>
+__device__ __forceinline__ R upwind(R a, R x, R y) { return a * sel_ge0(a, x, y); }
+template <typename R>
+__device__ __forceinline__ R pp(R y) { return dmax(R(0), y); }
+template <typename R>
+__device__ __forceinline__ R pn(R y) { return -dmin(R(0), y); }
 
-// n / d for the limiter ratios (:606-609).  d >= eps > 0 and everything is
-// finite there.  EXACT: the IEEE-correct quotient.  FAST (MPDATA_FAST_DIV):
-// reciprocal + two Newton steps + one residual correction, without the
-// scale/fixup handling of subnormal and huge operands the limiter never sees
-// (result within 1 ulp of the correctly rounded quotient).
-__device__ __forceinline__ double ratio(double n, double d) {
-#ifdef MPDATA_FAST_DIV
+// 1 / d for the FAST limiter ratios: hardware reciprocal + Newton steps (fp64: two, the
+// v_rcp_f64 seed is far from full precision; fp32: one), without the scale/fixup handling of
+// subnormal and huge operands the limiter never sees (d >= eps^2 > 0, finite).
+__device__ __forceinline__ double recip_nr(double d) {
   double r = __builtin_amdgcn_rcp(d);
   double e = __builtin_fma(-d, r, 1.0);
   r = __builtin_fma(r, e, r);
   e = __builtin_fma(-d, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  const double q = n * r;
-  const double rem = __builtin_fma(-d, q, n);
-  return __builtin_fma(rem, r, q);
-#else
-  return n / d;
-#endif
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ float recip_nr(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  return __builtin_fmaf(r, e, r);
+}
+__device__ __forceinline__ f32x2 recip_nr(f32x2 d) {
+  f32x2 r = f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f32x2 e = __builtin_elementwise_fma(-d, r, f32x2{1.0f, 1.0f});
+  return __builtin_elementwise_fma(r, e, r);
 }
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -104,23 +133,29 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0,
                                            (int)(unsigned)(bytes > lim ? lim : bytes), 0x00020000);
 }
-__device__ __forceinline__ double ld_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-#ifdef MPD2_ABL_NOMEM  // timing ablation only (wrong results)
-  return (double)(voff + soff);
-#endif
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
-}
 __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
-#ifdef MPD2_ABL_NOMEM
+#ifdef MPD2_ABL_NOMEM  // timing ablation only (wrong results)
   if (v != 1.2345e300) return;
 #endif
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x2 v) {
+#ifdef MPD2_ABL_NOMEM
+  if (v.x != 1.2345e30f) return;
+#endif
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+#ifdef MPD2_ABL_NOMEM
+  if (v != 1.2345e30f) return;
+#endif
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
 
 // ---- vertical neighbours by DPP (register crossbar in the VALU) ---------------
 // LDS-crossbar permutes (ds_bpermute) cost no VALU slot but ~5 LDS cycles per
 // CU each and, measured with in-kernel clock stamps, enough power that the chip
-// drops its clock by ~15 %; DPP moves are two 32-bit VALU passes per double.
+// drops its clock by ~15 %; DPP moves are one 32-bit VALU pass per register (two per double).
 // A lane without a source lane reads 0 (bound_ctrl), so the move needs no prior copy of
 // its destination (with bound_ctrl off the destination is an input -- "keep the old
 // value" -- and hipcc spends a v_mov per half to set it up).
@@ -130,21 +165,35 @@ __device__ __forceinline__ double dpp_mov(double src) {
   int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
+template <int CTRL>
+__device__ __forceinline__ f32x2 dpp_mov(f32x2 src) {
+  const u32x2 b = __builtin_bit_cast(u32x2, src);
+  u32x2 o;
+  o.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b.x, CTRL, 0xF, 0xF, true);
+  o.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b.y, CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(f32x2, o);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, 0xF, 0xF, true));
+}
 #define MPD_DPP_WAVE_SHL1 0x130
 #define MPD_DPP_WAVE_SHR1 0x138
 
 // value of lane-1 (level k-1); lane 0 reads 0
-__device__ __forceinline__ double shift_dn(double x) { return dpp_mov<MPD_DPP_WAVE_SHR1>(x); }
+template <typename R>
+__device__ __forceinline__ R shift_dn(R x) { return dpp_mov<MPD_DPP_WAVE_SHR1>(x); }
 // value of lane+1 (level k+1); lane 63 reads 0
-__device__ __forceinline__ double shift_up(double x) { return dpp_mov<MPD_DPP_WAVE_SHL1>(x); }
+template <typename R>
+__device__ __forceinline__ R shift_up(R x) { return dpp_mov<MPD_DPP_WAVE_SHL1>(x); }
 // ... with the clamps kb = max(1,k-1) / kc = min(nzm,k+1): `own` is the wave mask of the
-// lanes that keep their own value.  Select and move are ONE instruction per 32-bit half
+// lanes that keep their own value.  Select and move are ONE instruction per 32-bit register
 // (v_cndmask_b32 with a DPP source operand; hipcc emits v_mov_b32_dpp + v_cndmask_b32 for
 // the same thing written in C).  s_nop 1: a DPP operand written by the preceding VALU
 // instruction needs two wait states, which the compiler cannot see inside an asm block.
 // Executed by ALL lanes (under a divergent EXEC mask a switched-off source lane counts as
 // missing).
-#define MPD_CNDMASK_DPP(CTRL)                                                                  \
+#define MPD_CNDMASK_DPP64(CTRL)                                                                \
   int lo, hi;                                                                                  \
   const int xl = __double2loint(x), xh = __double2hiint(x);                                    \
   asm("s_mov_b64 vcc, %4\n\ts_nop 1\n\t"                                                      \
@@ -154,50 +203,85 @@ __device__ __forceinline__ double shift_up(double x) { return dpp_mov<MPD_DPP_WA
       : "v"(xl), "v"(xh), "s"(own)                                                             \
       : "vcc");                                                                                \
   return __hiloint2double(hi, lo);
+#define MPD_CNDMASK_DPP32(CTRL)                                                                \
+  int r;                                                                                       \
+  const int xi = __builtin_bit_cast(int, x);                                                   \
+  asm("s_mov_b64 vcc, %2\n\ts_nop 1\n\t"                                                      \
+      "v_cndmask_b32_dpp %0, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0"      \
+      : "=&v"(r)                                                                               \
+      : "v"(xi), "s"(own)                                                                      \
+      : "vcc");                                                                                \
+  return __builtin_bit_cast(float, r);
 __device__ __forceinline__ double shift_dn_clamped(double x, unsigned long long own) {
-  MPD_CNDMASK_DPP("wave_shr:1")
+  MPD_CNDMASK_DPP64("wave_shr:1")
 }
 __device__ __forceinline__ double shift_up_clamped(double x, unsigned long long own) {
-  MPD_CNDMASK_DPP("wave_shl:1")
+  MPD_CNDMASK_DPP64("wave_shl:1")
 }
-#undef MPD_CNDMASK_DPP
+__device__ __forceinline__ f32x2 shift_dn_clamped(f32x2 x, unsigned long long own) {
+  return __builtin_bit_cast(f32x2, shift_dn_clamped(__builtin_bit_cast(double, x), own));
+}
+__device__ __forceinline__ f32x2 shift_up_clamped(f32x2 x, unsigned long long own) {
+  return __builtin_bit_cast(f32x2, shift_up_clamped(__builtin_bit_cast(double, x), own));
+}
+__device__ __forceinline__ float shift_dn_clamped(float x, unsigned long long own) {
+  MPD_CNDMASK_DPP32("wave_shr:1")
+}
+__device__ __forceinline__ float shift_up_clamped(float x, unsigned long long own) {
+  MPD_CNDMASK_DPP32("wave_shl:1")
+}
+#undef MPD_CNDMASK_DPP64
+#undef MPD_CNDMASK_DPP32
 
-template <int LPS, int G_>
+template <typename R_, int LPS, int G_>
 struct TileV2 {
-  static constexpr int G = G_;                 // CRM instances per workgroup: rows of G*8 bytes
-  static constexpr int RPI = 32 / G_;          // rows moved by one DMA wave instruction (256 B)
+  using R = R_;
+  static constexpr int G = G_;                 // CRM instances per workgroup: rows of G*sizeof(R) bytes
+  static constexpr int ROWB = G_ * (int)sizeof(R_);   // bytes of a row segment (128 or 256)
+  static constexpr int RPI = 256 / ROWB;       // rows moved by one DMA wave instruction (256 B)
+  static constexpr int EPI = 256 / (int)sizeof(R_);   // elements moved by one DMA wave instruction
   static constexpr int SLP = 64 / LPS;         // instances per wave
   static constexpr int NWV = G_ / SLP;         // waves per workgroup
-  static constexpr int THREADS = 64 * NWV;     // = 16 * LPS
-  static constexpr int RS = G_ + 1;           // out tile: LDS row stride in doubles
+  static constexpr int THREADS = 64 * NWV;     // = G * LPS
+  static constexpr int RS = G_ + 1;            // out tile: LDS row stride in elements
   static constexpr int NZM_MAX = LPS - 1;
   static constexpr int NSLOT = 4;              // input ring: columns q .. q+3 (a 5-slot ring,
                                                // one more column in flight, measured 1.5 % slower)
-  static constexpr int ARR = LPS * G_;         // doubles of one array block (LPS rows x G)
+  static constexpr int ARR = LPS * G_;         // elements of one array block (LPS rows x G)
   static constexpr int IN_SLOT = 3 * ARR + G_; // f,u,w rows of one column + one row of zeros
   static constexpr int OUT_SLOT = NZM_MAX * RS;
-  static constexpr int LDS_DOUBLES = NSLOT * IN_SLOT + 2 * OUT_SLOT;
-  static constexpr int VM_PER_STEP = 7;        // 1 store + 6 DMA per wave and step
+  static constexpr int LDS_ELEMS = NSLOT * IN_SLOT + 2 * OUT_SLOT;
+  // DMA instructions per array, column and wave: the NZM_MAX rows of an array are
+  // ceil(NZM_MAX / RPI) instructions, dealt out over the NWV waves
+  static constexpr int NI_MAX = (NZM_MAX + RPI - 1) / RPI;
+  static constexpr int NIT = (NI_MAX + NWV - 1) / NWV;
+  static constexpr int VM_PER_STEP = 1 + 3 * NIT;  // 1 store + 3*NIT DMA per wave and step
+  // waves per SIMD the register budget must allow: 128 VGPRs (8-byte elements: 2 workgroups of
+  // 8 waves per CU at LPS = 32; one-instance-per-lane fp32: 1 workgroup of 16 waves)
+  static constexpr int MIN_WAVES = 4;
+  static_assert(ROWB == 128 || ROWB == 256, "row segments of 128 or 256 bytes");
+  static_assert(THREADS <= 1024 && NIT >= 1 && NIT <= 2, "workgroup shape");
 };
 
 // Rolling window: rings of 3 slots indexed by (column mod 3).
+template <typename R>
 struct Window {
-  double F0[3], PMX[3], PMN[3], U1[3], DW1[3];      // written for column q
-  double F1[3], F1D[3], F1U[3], MX0[3], MN0[3];     // written for column q-1
-  double UR[3], UD[3], PW[3], SW[3], WR[3];         // u, u(kb), w+w(kc), w-sum, w of column q
-  double SU[3], U2P[3], U2N[3];                     // written for column q-1 (pp / pn of U2)
-  double MXN[3], MNN[3], U3[3], DW3[3];             // written for column q-2
+  R F0[3], PMX[3], PMN[3], U1[3], DW1[3];      // written for column q
+  R F1[3], F1D[3], F1U[3], MX0[3], MN0[3];     // written for column q-1
+  R UR[3], UD[3], PW[3], SW[3], WR[3];         // u, u(kb), w+w(kc), w-sum, w of column q
+  R SU[3], U2P[3], U2N[3];                     // written for column q-1 (pp / pn of U2)
+  R MXN[3], MNN[3], U3[3], DW3[3];             // written for column q-2
 };
 
-template <int LPS, int G>
-__global__ void __launch_bounds__(G * LPS, 4)
-mpdata_advect_xmarch_kernel(const MpdataArgs a) {
-  using T = TileV2<LPS, G>;
+template <typename R, int LPS, int G>
+__global__ void __launch_bounds__(G * LPS, (TileV2<R, LPS, G>::MIN_WAVES))
+mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
+  using T = TileV2<R, LPS, G>;
   constexpr int RS = T::RS, SLP = T::SLP, RPI = T::RPI;
-  static_assert(G == 16 || G == 32, "row segments of 128 or 256 bytes");
-  __shared__ double lds[T::LDS_DOUBLES];
-  double* const in_slot0 = lds;
-  double* const out_slot0 = lds + T::NSLOT * T::IN_SLOT;
+  constexpr int RB = (int)sizeof(R);  // bytes per element
+  __shared__ R lds[T::LDS_ELEMS];
+  R* const in_slot0 = lds;
+  R* const out_slot0 = lds + T::NSLOT * T::IN_SLOT;
 
   const int nx = a.nx, nz = a.nz, nzm = nz - 1;
   const long long ncrms = a.ncrms;
@@ -211,8 +295,8 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   const unsigned grp = blockIdx.y;
   const long long sl_base = (long long)grp * G;
 
-  double* const f = a.f + (long long)tr * a.f_tstride;
-  double* const flux = a.flux + (long long)tr * a.flux_tstride;
+  R* const f = a.f + (long long)tr * a.f_tstride;
+  R* const flux = a.flux + (long long)tr * a.flux_tstride;
 
   // ---- compute-side mapping: lane -> (instance, level) ----------------------
   const int kk = lane % LPS;               // k - 1
@@ -225,22 +309,22 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   if (!slc_ok) sl_c = ncrms - 1;
 
   // per-lane constants (:552, :553, :565, :569)
-  const double eps = (double)1.e-10f;  // :509, fp32 literal
+  const R eps = (R)1.e-10f;  // :509, fp32 literal
   const long long kidx = sl_c + ncrms * (long long)(kl - 1);
-  const double RHO = a.rho[kidx];
-  const double adz_l = a.adz[kidx];
-  const double rhow_l = a.rhow[kidx];
-  const double IRHO = 1.0 / RHO;
-  const double IADZ = 1.0 / adz_l;
-  const double IRHOW = 1.0 / (rhow_l * adz_l);
+  const R RHO = a.rho[kidx];
+  const R adz_l = a.adz[kidx];
+  const R rhow_l = a.rhow[kidx];
+  const R IRHO = R(1) / RHO;
+  const R IADZ = R(1) / adz_l;
+  const R IRHOW = R(1) / (rhow_l * adz_l);
   // :569  dd = 2./(kc-kb)/adz = (2 or 1)*(1/adz) exactly; the factor 2 is applied as an
   // exponent step on dd*(...) (exact scaling, bit-identical)
   const int dd_exp = (k == 1 || k == nzm) ? 1 : 0;
 #ifdef MPDATA_FAST_DIV
-  const double KU = __builtin_ldexp(0.03125 * IRHO * IADZ, dd_exp);
+  const R KU = rldexp(R(0.03125) * IRHO * IADZ, dd_exp);
   // www(:,:,:,1) = 0 (:586) lives in the constant: at k = 1 the advective part of W2 is an
   // exact zero already (kb = k, f - f(kb) = 0), a zero KW removes the cross part
-  const double KW = (k == 1) ? 0.0 : 0.03125 * IRHO;
+  const R KW = (k == 1) ? R(0) : R(0.03125) * IRHO;
 #endif
   const bool k_is_1 = k == 1;
   const bool k_ge_nzm = k >= nzm;
@@ -261,31 +345,34 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   // that own nothing get an out-of-range offset: the buffer range check drops
   // their store, and every wave still issues the same number of stores.
   const unsigned OOB = 0xFFFFFFF8u;
-  const unsigned tf = (t_act && slt_ok) ? (unsigned)((sl_t + ncrms * (long long)(nx + 6) * t_rowc) * 8) : OOB;
-  const unsigned colb = (unsigned)(ncrms * 8);  // bytes between columns
-  const __amdgpu_buffer_rsrc_t rsf = make_rsrc(f, ncrms * 8ll * (nx + 6) * nzm);
-  const __amdgpu_buffer_rsrc_t rsu = make_rsrc(a.u, ncrms * 8ll * (nx + 5) * nzm);
-  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.w, ncrms * 8ll * (nx + 4) * nz);
+  const unsigned tf = (t_act && slt_ok) ? (unsigned)((sl_t + ncrms * (long long)(nx + 6) * t_rowc) * RB) : OOB;
+  const unsigned colb = (unsigned)(ncrms * RB);  // bytes between columns
+  const __amdgpu_buffer_rsrc_t rsf = make_rsrc(f, ncrms * (long long)RB * (nx + 6) * nzm);
+  const __amdgpu_buffer_rsrc_t rsu = make_rsrc(a.u, ncrms * (long long)RB * (nx + 5) * nzm);
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.w, ncrms * (long long)RB * (nx + 4) * nz);
 
-  // ---- DMA mapping: one wave instruction moves 256 bytes, 4 per lane = RPI rows
-  //      (G=16: two 128-byte rows, lanes 0-31 row 2j, lanes 32-63 row 2j+1; G=32: one row).  LDS image of a column:
-  //      [array][row][16 doubles], double (row, sl) stored at position
-  //      sl ^ ((row / rows-per-instruction) & (G-1)): the swizzle is applied to the SOURCE address.
+  // ---- DMA mapping: one wave instruction moves 256 bytes, 4 per lane = RPI rows of G
+  //      elements (128-B rows: two rows, lanes 0-31 row 2j, lanes 32-63 row 2j+1; 256-B rows:
+  //      one).  LDS image of a column: [array][row][G elements], element (row, sl) stored at
+  //      position sl ^ ((row / rows-per-instruction) & (G-1)): the swizzle is applied to the
+  //      SOURCE address.
   const int ni = (nzm + RPI - 1) / RPI;  // DMA instructions per array and column
-  unsigned vdf[2], vdu[2], vdw[2];  // per-lane source byte offsets of the wave's two instructions
-  int jd[2];
+  constexpr int LPR = T::ROWB / 4;       // lanes (dwords) per row
+  constexpr int DPE = RB / 4;            // dwords per element
+  unsigned vdf[T::NIT], vdu[T::NIT], vdw[T::NIT];  // per-lane source byte offsets of the wave's instructions
+  int jd[T::NIT];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < T::NIT; ++it) {
     const int j = min(wave + it * T::NWV, ni - 1);  // (a clamped duplicate rewrites the same bytes)
     jd[it] = j;
-    const int row = min(j * RPI + lane / (2 * G), nzm - 1);
-    const int p = (lane % (2 * G)) >> 1;
+    const int row = min(j * RPI + lane / LPR, nzm - 1);
+    const int p = (lane % LPR) / DPE;
     long long sl_d = sl_base + (p ^ (j & (G - 1)));
     if (sl_d >= ncrms) sl_d = ncrms - 1;
-    const unsigned part = (lane & 1) * 4;
-    vdf[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 6) * row) * 8) + part;
-    vdu[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 5) * row) * 8) + part;
-    vdw[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 4) * row) * 8) + part;
+    const unsigned part = (lane % DPE) * 4;
+    vdf[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 6) * row) * RB) + part;
+    vdu[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 5) * row) * RB) + part;
+    vdw[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 4) * row) * RB) + part;
   }
   // compute-side read position inside one array block of a slot
   auto lds_pos = [&](int level) __attribute__((always_inline)) {  // position of (level, this instance)
@@ -299,8 +386,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
   // w of the lanes above nzm (ghost level nz and dead lanes) is 0: they read the zero row of the slot
   const int c_lds_w = lvl_ok ? 2 * T::ARR + c_lds : 3 * T::ARR + sl_l;
 
-  // direct (untransposed) store of a finished column: lane (instance, level) writes its own 8 bytes
-  const unsigned vst = (lvl_ok && slc_ok) ? (unsigned)((sl_c + ncrms * (long long)(nx + 6) * (k - 1)) * 8) : OOB;
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   // all DMA of column `col` into its ring slot (6 instructions per wave)
@@ -311,10 +396,10 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     const unsigned cf = colb * (unsigned)(min(max(col, -2), nx + 3) + 2);
     const unsigned cu = colb * (unsigned)(min(max(col, -1), nx + 3) + 1);
     const unsigned cw = colb * (unsigned)(min(max(col, -1), nx + 2) + 1);
-    double* slot = in_slot0 + (col & (T::NSLOT - 1)) * T::IN_SLOT;
+    R* slot = in_slot0 + (col & (T::NSLOT - 1)) * T::IN_SLOT;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      double* d = slot + jd[it] * 32;  // 256 bytes per instruction
+    for (int it = 0; it < T::NIT; ++it) {
+      R* d = slot + jd[it] * T::EPI;  // 256 bytes per instruction
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, 0);
@@ -343,15 +428,15 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 #else
 #define STAMP() ((void)0)
 #endif
-  Window S;
+  Window<R> S;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    S.F0[j] = S.PMX[j] = S.PMN[j] = S.U1[j] = S.DW1[j] = 0.0;
-    S.F1[j] = S.F1D[j] = S.F1U[j] = S.MX0[j] = S.MN0[j] = 0.0;
-    S.UR[j] = S.UD[j] = S.PW[j] = S.SW[j] = S.WR[j] = S.SU[j] = S.U2P[j] = S.U2N[j] = 0.0;
-    S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = 0.0;
+    S.F0[j] = S.PMX[j] = S.PMN[j] = S.U1[j] = S.DW1[j] = R(0);
+    S.F1[j] = S.F1D[j] = S.F1U[j] = S.MX0[j] = S.MN0[j] = R(0);
+    S.UR[j] = S.UD[j] = S.PW[j] = S.SW[j] = S.WR[j] = S.SU[j] = S.U2P[j] = S.U2N[j] = R(0);
+    S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = R(0);
   }
-  double S1 = 0, S3 = 0;
+  R S1 = R(0), S3 = R(0);
 
   // One step of the march.  PH = (q+2) mod 3 selects the ring slots at compile
   // time; FULL = steady state (4 <= q <= nx): every stage is active.
@@ -363,8 +448,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     // column q landed (this wave's DMA of it is 2 steps = 14 vector-memory ops
     // old), out tile of column q-4 written: then everyone's are, after the barrier
     STAMP();
-    static_assert(T::NSLOT == 4 && T::VM_PER_STEP == 7, "the counted wait below assumes them");
-    asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+    static_assert(T::NSLOT == 4 && (T::VM_PER_STEP == 7 || T::VM_PER_STEP == 4), "the counted waits below assume them");
+    if constexpr (T::VM_PER_STEP == 7) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     STAMP();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -372,31 +458,35 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 
 
     // ---- this column, transposed: lanes along k -------------------------------
-    const double* s = in_slot0 + (q & (T::NSLOT - 1)) * T::IN_SLOT;
-    const double f0q = s[c_lds];
-    const double uq = s[T::ARR + c_lds];
-    const double wq = s[c_lds_w];  // ghost level: w = 0 (zero row)
+    const R* s = in_slot0 + (q & (T::NSLOT - 1)) * T::IN_SLOT;
+    const R f0q = s[c_lds];
+    const R uq = s[T::ARR + c_lds];
+    const R wq = s[c_lds_w];  // ghost level: w = 0 (zero row)
 
 #ifdef MPD2_ABL_NOCOMPUTE  // timing ablation only: data movement without the arithmetic
     if (q - 3 >= -1 && q - 3 <= nx + 2 && lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = f0q + uq + wq;
+    asm volatile("" ::: "memory");
+    st_row(rsf, (q - 4 >= -1 && q - 4 <= nx + 2) ? tf : OOB, colb * (unsigned)max(q - 4 + 2, 0),
+           out_slot0[((q - 1) & 1) * T::OUT_SLOT + t_lds]);
+    dma_col(q + T::NSLOT - 1);
     return;
 #endif
 #define DN_C(x) shift_dn_clamped((x), own_dn)
 #define DN_P(x) shift_dn(x)
 #define UP_C(x) shift_up_clamped((x), own_up)
 #define UP_G(x) shift_up(x)
-    const double f0d = s[c_dn];
-    const double f0u = s[c_up];
-    const double F0p = S.F0[C1];
+    const R f0d = s[c_dn];
+    const R f0u = s[c_up];
+    const R F0p = S.F0[C1];
 
     // ================= stage A =================================================
     // (every ring slot is written unconditionally so that the slot of column
     //  q-3 is dead afterwards: inactive stages store zeros)
-    double U1q = 0.0, DW1q = 0.0, f1_1 = 0.0, F1D_1 = 0.0, F1U_1 = 0.0, MX0_1 = 0.0, MN0_1 = 0.0;
+    R U1q = R(0), DW1q = R(0), f1_1 = R(0), F1D_1 = R(0), F1U_1 = R(0), MX0_1 = R(0), MN0_1 = R(0);
     if (FULL || (q >= -1 && q <= nx + 3)) {
       U1q = upwind(uq, F0p, f0q);  // :532
       if (FULL || q <= nx + 2) {
-        const double W1q = upwind(wq, f0d, f0q);  // :537
+        const R W1q = upwind(wq, f0d, f0q);  // :537
         DW1q = UP_G(W1q) - W1q;
         if (FULL || (q >= 1 && q <= nx)) S1 = S1 + W1q;  // :545
       }
@@ -421,8 +511,8 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     S.F0[C0] = f0q;
 
     // u / w sums for the antidiffusive cross terms (:573, :582), reference order
-    const double ud = s[T::ARR + c_dn];
-    const double wu = s[2 * T::ARR + c_up];
+    const R ud = s[T::ARR + c_dn];
+    const R wu = s[2 * T::ARR + c_up];
 #ifdef MPDATA_FAST_DIV
     S.UD[C0] = uq + ud;                        // (the ring holds the pair sum here)
     S.SU[C1] = S.UD[C1] + S.UD[C0];
@@ -439,19 +529,19 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 
     STAMP();
     // ================= stage B/C ===============================================
-    double U2_1 = 0.0, U2p_1 = 0.0, U2n_1 = 0.0, W2_2 = 0.0, W2p = 0.0, W2n = 0.0, MXN_2 = 0.0, MNN_2 = 0.0;
+    R U2_1 = R(0), U2p_1 = R(0), U2n_1 = R(0), W2_2 = R(0), W2p = R(0), W2n = R(0), MXN_2 = R(0), MNN_2 = R(0);
     if (FULL || (q >= 1 && q <= nx + 3)) {
       {  // :571-573, column q-1
 #ifdef MPDATA_FAST_DIV
         // FAST: the constant factors 0.03125 * irho * dd of the cross term are one per-lane
         // constant (same real-arithmetic value, 3 operations fewer)
-        const double u1 = S.UR[C1];
-        const double t1 = __builtin_fabs(u1) - (u1 * u1) * IRHO;
-        const double x4 = S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1;
-        U2_1 = 0.5 * (t1 * (f1_1 - S.F1[C2])) - KU * ((u1 * S.SW[C1]) * x4);
+        const R u1 = S.UR[C1];
+        const R t1 = rabs(u1) - (u1 * u1) * IRHO;
+        const R x4 = S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1;
+        U2_1 = R(0.5) * (t1 * (f1_1 - S.F1[C2])) - KU * ((u1 * S.SW[C1]) * x4);
 #else
-        const double ad = andiff(S.F1[C2], f1_1, S.UR[C1], IRHO);
-        const double x = __builtin_ldexp(IADZ * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1), dd_exp);
+        const R ad = andiff(S.F1[C2], f1_1, S.UR[C1], IRHO);
+        const R x = rldexp(IADZ * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1), dd_exp);
         U2_1 = ad - across(x, S.UR[C1], S.SW[C1]) * IRHO;
 #endif
         U2p_1 = pp(U2_1);
@@ -460,40 +550,36 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
       if (FULL || q >= 2) {  // column q-2
         {  // :580-582, :586
 #ifdef MPDATA_FAST_DIV
-          const double w2 = S.WR[C2];
-          const double t1 = __builtin_fabs(w2) - (w2 * w2) * IRHOW;
-          const double x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
-          W2_2 = 0.5 * (t1 * (S.F1[C2] - S.F1D[C2])) - KW * ((w2 * S.SU[C2]) * x4);  // k = 1: 0
+          const R w2 = S.WR[C2];
+          const R t1 = rabs(w2) - (w2 * w2) * IRHOW;
+          const R x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
+          W2_2 = R(0.5) * (t1 * (S.F1[C2] - S.F1D[C2])) - KW * ((w2 * S.SU[C2]) * x4);  // k = 1: 0
 #else
-          const double ad = andiff(S.F1D[C2], S.F1[C2], S.WR[C2], IRHOW);
-          const double x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
-          const double v = ad - across(x, S.WR[C2], S.SU[C2]) * IRHO;
-          W2_2 = k_is_1 ? 0.0 : v;  // www(:,:,:,1) = 0 (:586)
+          const R ad = andiff(S.F1D[C2], S.F1[C2], S.WR[C2], IRHOW);
+          const R x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
+          const R v = ad - across(x, S.WR[C2], S.SU[C2]) * IRHO;
+          W2_2 = k_is_1 ? R(0) : v;  // www(:,:,:,1) = 0 (:586)
 #endif
         }
-        const double W2u = UP_C(W2_2);
+        const R W2u = UP_C(W2_2);
         // :596-597
-        const double mx1 = dmax(dmax(dmax(dmax(dmax(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MX0[C2]);
-        const double mn1 = dmin(dmin(dmin(dmin(dmin(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MN0[C2]);
+        const R mx1 = dmax(dmax(dmax(dmax(dmax(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MX0[C2]);
+        const R mn1 = dmin(dmin(dmin(dmin(dmin(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MN0[C2]);
         // :606-609
         W2p = pp(W2_2);
         W2n = pn(W2_2);
-        const double num_mx = RHO * (mx1 - S.F1[C2]);
-        const double den_mx = U2n_1 + S.U2P[C2] + IADZ * (pn(W2u) + W2p) + eps;
-        const double num_mn = RHO * (S.F1[C2] - mn1);
-        const double den_mn = U2p_1 + S.U2N[C2] + IADZ * (pp(W2u) + W2n) + eps;
+        const R num_mx = RHO * (mx1 - S.F1[C2]);
+        const R den_mx = U2n_1 + S.U2P[C2] + IADZ * (pn(W2u) + W2p) + eps;
+        const R num_mn = RHO * (S.F1[C2] - mn1);
+        const R den_mn = U2p_1 + S.U2N[C2] + IADZ * (pp(W2u) + W2n) + eps;
 #ifdef MPDATA_FAST_DIV
         // FAST: one reciprocal for both ratios, r = 1/(den_mx*den_mn) (both >= eps = 1e-10,
         // finite), two Newton steps, then a/b = a * (other denominator) * r.
         // (Forming the denominators as (S -+ D)/2 from |.|-sums would save 5 operations but
         //  cancels: on the reference-raw input law it costs 4 digits of the rel-L1 agreement.)
         {
-          const double dd2 = den_mx * den_mn;
-          double r = __builtin_amdgcn_rcp(dd2);
-          double e = __builtin_fma(-dd2, r, 1.0);
-          r = __builtin_fma(r, e, r);
-          e = __builtin_fma(-dd2, r, 1.0);
-          r = __builtin_fma(r, e, r);
+          const R dd2 = den_mx * den_mn;
+          const R r = recip_nr(dd2);
           MXN_2 = num_mx * (den_mn * r);
           MNN_2 = num_mn * (den_mx * r);
         }
@@ -502,8 +588,8 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
         MNN_2 = num_mn / den_mn;
 #endif
         // the ratios are only ever used as min(1, ratio, ...) (:618, :623): keep them clamped
-        MXN_2 = dmin(1.0, MXN_2);
-        MNN_2 = dmin(1.0, MNN_2);
+        MXN_2 = dmin(R(1), MXN_2);
+        MNN_2 = dmin(R(1), MNN_2);
       }
     }
     S.U2P[C1] = U2p_1;
@@ -512,13 +598,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     S.MNN[C2] = MNN_2;
 
     // ================= stage D =================================================
-    double U3_2 = 0.0, DW3_2 = 0.0;
+    R U3_2 = R(0), DW3_2 = R(0);
     if (FULL || (q >= 3 && q <= nx + 3)) {
       U3_2 = S.U2P[C2] * dmin(MXN_2, S.MNN[C3]) - S.U2N[C2] * dmin(S.MXN[C3], MNN_2);  // :618
       if (FULL || q <= nx + 2) {
-        const double mxd = DN_C(MXN_2);
-        const double mnd = DN_C(MNN_2);
-        const double W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
+        const R mxd = DN_C(MXN_2);
+        const R mnd = DN_C(MNN_2);
+        const R W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
         S3 = S3 + W3;  // :624
         DW3_2 = UP_G(W3) - W3;
       }
@@ -526,9 +612,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
     {
       const int n = q - 3;  // column finished in this step
       if (FULL || (n >= -1 && n <= nx + 2)) {
-        double v = S.F1[C3];  // halo columns keep the first-pass value (:557)
+        R v = S.F1[C3];  // halo columns keep the first-pass value (:557)
         if (FULL || (n >= 1 && n <= nx))
-          v = dmax(0.0, S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
+          v = dmax(R(0), S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
         if (lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = v;
       }
     }
@@ -563,13 +649,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
 
   const int q_first = -2;
   // the zero row of every ring slot (never touched by the DMA)
-  if (tid < T::NSLOT * G) in_slot0[(tid / G) * T::IN_SLOT + 3 * T::ARR + (tid % G)] = 0.0;
+  if (tid < T::NSLOT * G) in_slot0[(tid / G) * T::IN_SLOT + 3 * T::ARR + (tid % G)] = R(0);
 
   // columns -2, -1, 0 into flight, each behind a dropped store so that the
   // counted wait of the first steps sees the steady-state op pattern
 #pragma unroll
   for (int c = q_first; c < q_first + T::NSLOT - 1; ++c) {
-    st_row(rsf, OOB, 0, 0.0);
+    st_row(rsf, OOB, 0, R(0));
     dma_col(c);
   }
 
@@ -607,9 +693,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgs a) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      double* const tA = out_slot0 + (qe & 1) * T::OUT_SLOT;
-      double* const tB = out_slot0 + ((qe & 1) ^ 1) * T::OUT_SLOT;
-      double* const tC = in_slot0;
+      R* const tA = out_slot0 + (qe & 1) * T::OUT_SLOT;
+      R* const tB = out_slot0 + ((qe & 1) ^ 1) * T::OUT_SLOT;
+      R* const tC = in_slot0;
       if (lvl_ok) {
         tB[(k - 1) * RS + sl_l] = S.F1[C2];  // halo columns keep the first-pass value (:557)
         tC[(k - 1) * RS + sl_l] = S.F1[C1];

@@ -37,21 +37,35 @@ static void launch_tile(const MpdataArgs& a, int ntracers, void* stream) {
   X(23, 64, 16)            \
   X(24, 32, 32)
 
-template <int LPS, int G>
-static void launch_tile_v2(const MpdataArgs& a, int ntracers, void* stream) {
-  using T = v2::TileV2<LPS, G>;
+// fp32 x-marching kernels, one instance per lane: 32 instances per workgroup = 128-byte rows
+// (any ncrms; 16 waves per workgroup at LPS = 32)
+#define MPDATA_TILES_V2_F32(X) \
+  X(30, 8, 32)                 \
+  X(31, 16, 32)                \
+  X(32, 32, 32)
+// fp32 x-marching kernels, two adjacent instances per lane (packed fp32 arithmetic): id, LPS,
+// G in PAIRS (16 pairs = 32 instances = 128-byte rows).  Even ncrms only.
+#define MPDATA_TILES_V2_F32X2(X) \
+  X(40, 8, 16)                   \
+  X(41, 16, 16)                  \
+  X(42, 32, 16)                  \
+  X(43, 64, 16)
+
+template <typename R, int LPS, int G>
+static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) {
+  using T = v2::TileV2<R, LPS, G>;
   const unsigned groups = (unsigned)((a.ncrms + G - 1) / G);
   dim3 grid((unsigned)ntracers, groups, 1), block(T::THREADS, 1, 1);  // tracer fastest
-  hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<LPS, G>), grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G>), grid, block, 0, (hipStream_t)stream, a);
 }
 
-int max_tile_id() { return 24; }
+int max_tile_id() { return 43; }
 
 bool tile_info(int id, MpdataTileInfo* info) {
 #define X(ID, W_, SPW_, NWV_)                                                     \
   if (id == ID) {                                                                 \
     using T = Tile<W_, SPW_, NWV_>;                                               \
-    *info = MpdataTileInfo{ID, W_, SPW_, NWV_, T::SLW, T::NCOL, 1 << 30, T::THREADS, \
+    *info = MpdataTileInfo{ID, W_, SPW_, NWV_, T::SLW, T::NCOL, 1 << 30, 8, T::THREADS, \
                            "kmarch_W" #W_ "_SPW" #SPW_ "_NWV" #NWV_};             \
     return true;                                                                  \
   }
@@ -59,12 +73,30 @@ bool tile_info(int id, MpdataTileInfo* info) {
 #undef X
 #define X(ID, LPS_, G_)                                                                  \
   if (id == ID) {                                                                        \
-    using T = v2::TileV2<LPS_, G_>;                                                      \
-    *info = MpdataTileInfo{ID, 0, 0, T::NWV, G_, 1 << 30, LPS_, T::THREADS,              \
+    using T = v2::TileV2<double, LPS_, G_>;                                              \
+    *info = MpdataTileInfo{ID, 0, 0, T::NWV, G_, 1 << 30, LPS_, 8, T::THREADS,           \
                            "xmarch_LPS" #LPS_ "_G" #G_};                                 \
     return true;                                                                         \
   }
   MPDATA_TILES_V2(X)
+#undef X
+#define X(ID, LPS_, G_)                                                                  \
+  if (id == ID) {                                                                        \
+    using T = v2::TileV2<float, LPS_, G_>;                                               \
+    *info = MpdataTileInfo{ID, 0, 0, T::NWV, G_, 1 << 30, LPS_, 4, T::THREADS,           \
+                           "xmarch_f32_LPS" #LPS_ "_G" #G_};                             \
+    return true;                                                                         \
+  }
+  MPDATA_TILES_V2_F32(X)
+#undef X
+#define X(ID, LPS_, G_)                                                                  \
+  if (id == ID) {                                                                        \
+    using T = v2::TileV2<v2::f32x2, LPS_, G_>;                                           \
+    *info = MpdataTileInfo{ID, 0, 0, T::NWV, 2 * G_, 1 << 30, LPS_, 4, T::THREADS,       \
+                           "xmarch_f32x2_LPS" #LPS_ "_G" #G_};                           \
+    return true;                                                                         \
+  }
+  MPDATA_TILES_V2_F32X2(X)
 #undef X
   return false;
 }
@@ -77,13 +109,45 @@ bool launch(int id, const MpdataArgs& a, int ntracers, void* stream) {
   }
   MPDATA_TILES(X)
 #undef X
-#define X(ID, LPS_, G_)                           \
-  if (id == ID) {                                 \
-    launch_tile_v2<LPS_, G_>(a, ntracers, stream); \
-    return true;                                  \
+#define X(ID, LPS_, G_)                                    \
+  if (id == ID) {                                          \
+    launch_tile_v2<double, LPS_, G_>(a, ntracers, stream); \
+    return true;                                           \
   }
   MPDATA_TILES_V2(X)
 #undef X
+  return false;
+}
+
+bool launch_f32(int id, const MpdataArgsF32& a, int ntracers, void* stream) {
+#define X(ID, LPS_, G_)                                   \
+  if (id == ID) {                                         \
+    launch_tile_v2<float, LPS_, G_>(a, ntracers, stream); \
+    return true;                                          \
+  }
+  MPDATA_TILES_V2_F32(X)
+#undef X
+  // two instances per lane: the same arrays seen as ncrms/2 pairs of adjacent instances
+  if (id >= 40 && (a.ncrms & 1) == 0) {
+    MpdataArgsT<v2::f32x2> p;
+    p.f = reinterpret_cast<v2::f32x2*>(a.f);
+    p.u = reinterpret_cast<const v2::f32x2*>(a.u);
+    p.w = reinterpret_cast<const v2::f32x2*>(a.w);
+    p.rho = reinterpret_cast<const v2::f32x2*>(a.rho);
+    p.rhow = reinterpret_cast<const v2::f32x2*>(a.rhow);
+    p.adz = reinterpret_cast<const v2::f32x2*>(a.adz);
+    p.flux = reinterpret_cast<v2::f32x2*>(a.flux);
+    p.ncrms = a.ncrms / 2; p.nx = a.nx; p.nz = a.nz;
+    p.f_tstride = a.f_tstride / 2; p.flux_tstride = a.flux_tstride / 2;
+    p.dbg = a.dbg;
+#define X(ID, LPS_, G_)                                        \
+  if (id == ID) {                                              \
+    launch_tile_v2<v2::f32x2, LPS_, G_>(p, ntracers, stream);  \
+    return true;                                               \
+  }
+    MPDATA_TILES_V2_F32X2(X)
+#undef X
+  }
   return false;
 }
 

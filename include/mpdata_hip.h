@@ -105,7 +105,25 @@ int mpdata_pack_shard_device(const double* full, double* shard, int64_t rows, in
 int mpdata_unpack_shard_device(double* full, const double* shard, int64_t rows, int64_t ncrms,
                                int64_t sl0, int64_t nloc, void* stream);
 
-/* ---- 6. Misc. */
+/* ---- 6. fp32: the reference's precision switch (`rp`, reference :12-13; note that the
+ * `selected_real_kind(7)` it asks for is fp64 on conforming compilers -- IEEE single is
+ * `selected_real_kind(6)`).  Same array contract with 4-byte reals.  Kernels cover nz <= 64
+ * for even ncrms (two adjacent instances per lane, packed fp32 arithmetic) and nz <= 32 for
+ * odd ncrms.  EXACT variant: f bit-identical to an fp32 build of the reference. */
+int mpdata_advect_scalar2d_f32(int64_t ncrms, int nx, int nz, int ntracers,
+                               float* f, const float* u, const float* w,
+                               const float* rho, const float* rhow,
+                               const float* adz, float* flux);
+int mpdata_advect_scalar2d_f32_device(int64_t ncrms, int nx, int nz, int ntracers,
+                                      float* f, const float* u, const float* w,
+                                      const float* rho, const float* rhow,
+                                      const float* adz, float* flux, void* stream);
+int mpdata_fill_synthetic_f32_device(float* a, int sid, int64_t rows, int64_t ncrms_global,
+                                     int64_t sl0, int64_t nloc, uint64_t seed, int dist,
+                                     void* stream);
+int64_t mpdata_algorithmic_bytes_f32(int64_t ncrms, int nx, int nz, int ntracers);
+
+/* ---- 7. Misc. */
 int mpdata_set_variant(int variant);      /* MPDATA_VARIANT_*; returns previous */
 int mpdata_get_variant(void);
 int mpdata_set_tile(int tile);            /* kernel tiling id; -1 = default */
