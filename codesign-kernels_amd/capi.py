@@ -84,6 +84,12 @@ def lib():
         L.mpdata_fill_synthetic_f32_device.argtypes = [dp, ci, i64, i64, i64, i64, ctypes.c_uint64, ci, vp]
         L.mpdata_algorithmic_bytes_f32.restype = i64
         L.mpdata_algorithmic_bytes_f32.argtypes = [i64, ci, ci, ci]
+        L.mpdata_plan_create_f32.restype = ci
+        L.mpdata_plan_create_f32.argtypes = [i64, ci, ci, ci, ctypes.POINTER(vp)]
+        L.mpdata_plan_upload_f32.restype = ci
+        L.mpdata_plan_upload_f32.argtypes = [vp] + [dp] * 7
+        L.mpdata_plan_download_f32.restype = ci
+        L.mpdata_plan_download_f32.argtypes = [vp, dp, dp]
         L.mpdata_set_variant.restype = ci
         L.mpdata_set_variant.argtypes = [ci]
         L.mpdata_get_variant.restype = ci
@@ -212,15 +218,20 @@ class Plan:
     """Library-owned device buffers + stream (reference: `!$acc enter data`,
     `update device`, `wait`, `update host`; :105-110, :237-242)."""
 
-    def __init__(self, ncrms, nx, nz, ntracers=1):
+    def __init__(self, ncrms, nx, nz, ntracers=1, dtype=np.float64):
         self._p = ctypes.c_void_p()
-        _check(lib().mpdata_plan_create(ncrms, nx, nz, ntracers, ctypes.byref(self._p)))
+        self._dt = np.dtype(dtype).type
+        if self._dt not in (np.float64, np.float32):
+            raise MpdataError(-1, f"Plan: dtype {dtype} is neither float64 nor float32")
+        self._sfx = "" if self._dt == np.float64 else "_f32"
+        _check(getattr(lib(), "mpdata_plan_create" + self._sfx)(ncrms, nx, nz, ntracers, ctypes.byref(self._p)))
 
     def upload(self, f, u, w, rho, rhow, adz, flux=None):
-        fl = _host_ptr(flux, "flux") if flux is not None else None
-        _check(lib().mpdata_plan_upload(self._p, _host_ptr(f, "f"), _host_ptr(u, "u"),
-                                        _host_ptr(w, "w"), _host_ptr(rho, "rho"),
-                                        _host_ptr(rhow, "rhow"), _host_ptr(adz, "adz"), fl))
+        dt = self._dt
+        fl = _host_ptr(flux, "flux", False, dt) if flux is not None else None
+        _check(getattr(lib(), "mpdata_plan_upload" + self._sfx)(
+            self._p, _host_ptr(f, "f", False, dt), _host_ptr(u, "u", False, dt), _host_ptr(w, "w", False, dt),
+            _host_ptr(rho, "rho", False, dt), _host_ptr(rhow, "rhow", False, dt), _host_ptr(adz, "adz", False, dt), fl))
 
     def run(self):
         _check(lib().mpdata_plan_run(self._p))
@@ -229,8 +240,8 @@ class Plan:
         _check(lib().mpdata_plan_sync(self._p))
 
     def download(self, f, flux):
-        _check(lib().mpdata_plan_download(self._p, _host_ptr(f, "f", True),
-                                          _host_ptr(flux, "flux", True)))
+        _check(getattr(lib(), "mpdata_plan_download" + self._sfx)(
+            self._p, _host_ptr(f, "f", True, self._dt), _host_ptr(flux, "flux", True, self._dt)))
 
     def last_kernel_ms(self):
         ms = ctypes.c_double()

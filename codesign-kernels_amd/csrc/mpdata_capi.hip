@@ -233,8 +233,9 @@ int fill_device(R* a, int sid, int64_t rows, int64_t ncrms_global, int64_t sl0, 
 struct mpdata_plan {
   int64_t ncrms;
   int nx, nz, ntracers;
+  int eb;  // bytes per real: 8 (fp64 plan) or 4 (fp32 plan)
   Sizes sz;
-  double *f, *u, *w, *rho, *rhow, *adz, *flux;
+  void *f, *u, *w, *rho, *rhow, *adz, *flux;
   hipStream_t stream;
   hipEvent_t ev0, ev1;
   bool uploaded, ran;
@@ -256,26 +257,26 @@ int mpdata_advect_scalar2d_f32_device(int64_t ncrms, int nx, int nz, int ntracer
   return advect_device<float>(ncrms, nx, nz, ntracers, f, u, w, rho, rhow, adz, flux, stream);
 }
 
-int mpdata_plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan) {
+static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan, int eb) {
   if (!plan) return set_err(MPDATA_EINVAL, "null plan pointer");
   *plan = nullptr;
   int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
   MpdataTileInfo t;
-  rc = choose_tile(variant(), ncrms, nx, nz, &t);
+  rc = choose_tile(variant(), ncrms, nx, nz, &t, eb);
   if (rc) return rc;
   mpdata_plan* p = (mpdata_plan*)calloc(1, sizeof(mpdata_plan));
   if (!p) return set_err(MPDATA_EINVAL, "out of host memory");
-  p->ncrms = ncrms; p->nx = nx; p->nz = nz; p->ntracers = ntracers;
+  p->ncrms = ncrms; p->nx = nx; p->nz = nz; p->ntracers = ntracers; p->eb = eb;
   p->sz = sizes_of(ncrms, nx, nz, ntracers);
   hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = hipMalloc((void**)&p->f, p->sz.f * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->u, p->sz.u * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->w, p->sz.w * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->rho, p->sz.k * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->rhow, p->sz.kz * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->adz, p->sz.k * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->flux, p->sz.kz * ntracers * 8);
+  if (e == hipSuccess) e = hipMalloc(&p->f, p->sz.f * eb);
+  if (e == hipSuccess) e = hipMalloc(&p->u, p->sz.u * eb);
+  if (e == hipSuccess) e = hipMalloc(&p->w, p->sz.w * eb);
+  if (e == hipSuccess) e = hipMalloc(&p->rho, p->sz.k * eb);
+  if (e == hipSuccess) e = hipMalloc(&p->rhow, p->sz.kz * eb);
+  if (e == hipSuccess) e = hipMalloc(&p->adz, p->sz.k * eb);
+  if (e == hipSuccess) e = hipMalloc(&p->flux, p->sz.kz * ntracers * eb);
   if (e == hipSuccess) e = hipStreamCreate(&p->stream);
   if (e == hipSuccess) e = hipEventCreate(&p->ev0);
   if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -286,35 +287,58 @@ int mpdata_plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   *plan = p;
   return 0;
 }
+int mpdata_plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan) {
+  return plan_create(ncrms, nx, nz, ntracers, plan, 8);
+}
+int mpdata_plan_create_f32(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan) {
+  return plan_create(ncrms, nx, nz, ntracers, plan, 4);
+}
 
-int mpdata_plan_upload(mpdata_plan* p, const double* f, const double* u, const double* w,
-                       const double* rho, const double* rhow, const double* adz,
-                       const double* flux) {
+static int plan_upload(mpdata_plan* p, const void* f, const void* u, const void* w, const void* rho,
+                       const void* rhow, const void* adz, const void* flux, int eb) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (p->eb != eb) return set_err(MPDATA_ESTATE, "plan precision (%d-byte reals) does not match the call", p->eb);
   if (!f || !u || !w || !rho || !rhow || !adz) return set_err(MPDATA_EINVAL, "null array pointer");
-  HIP_TRY(hipMemcpyAsync(p->f, f, p->sz.f * 8, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->u, u, p->sz.u * 8, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->w, w, p->sz.w * 8, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->rho, rho, p->sz.k * 8, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->rhow, rhow, p->sz.kz * 8, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->adz, adz, p->sz.k * 8, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->f, f, p->sz.f * eb, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->u, u, p->sz.u * eb, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->w, w, p->sz.w * eb, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->rho, rho, p->sz.k * eb, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->rhow, rhow, p->sz.kz * eb, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->adz, adz, p->sz.k * eb, hipMemcpyHostToDevice, p->stream));
   // flux is intent(out) in the reference but its level nz is never written
   // (reference :541, :624 touch 1..nzm only): carry the caller's values over
   if (flux)
-    HIP_TRY(hipMemcpyAsync(p->flux, flux, p->sz.kz * p->ntracers * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->flux, flux, p->sz.kz * p->ntracers * eb, hipMemcpyHostToDevice, p->stream));
   else
-    HIP_TRY(hipMemsetAsync(p->flux, 0, p->sz.kz * p->ntracers * 8, p->stream));
+    HIP_TRY(hipMemsetAsync(p->flux, 0, p->sz.kz * p->ntracers * eb, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   p->uploaded = true;
   return 0;
+}
+int mpdata_plan_upload(mpdata_plan* p, const double* f, const double* u, const double* w,
+                       const double* rho, const double* rhow, const double* adz,
+                       const double* flux) {
+  return plan_upload(p, f, u, w, rho, rhow, adz, flux, 8);
+}
+int mpdata_plan_upload_f32(mpdata_plan* p, const float* f, const float* u, const float* w,
+                           const float* rho, const float* rhow, const float* adz,
+                           const float* flux) {
+  return plan_upload(p, f, u, w, rho, rhow, adz, flux, 4);
 }
 
 int mpdata_plan_run(mpdata_plan* p) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run before mpdata_plan_upload");
   HIP_TRY(hipEventRecord(p->ev0, p->stream));
-  int rc = mpdata_advect_scalar2d_device(p->ncrms, p->nx, p->nz, p->ntracers, p->f, p->u, p->w,
-                                         p->rho, p->rhow, p->adz, p->flux, (void*)p->stream);
+  int rc;
+  if (p->eb == 8)
+    rc = mpdata_advect_scalar2d_device(p->ncrms, p->nx, p->nz, p->ntracers, (double*)p->f, (const double*)p->u,
+                                       (const double*)p->w, (const double*)p->rho, (const double*)p->rhow,
+                                       (const double*)p->adz, (double*)p->flux, (void*)p->stream);
+  else
+    rc = mpdata_advect_scalar2d_f32_device(p->ncrms, p->nx, p->nz, p->ntracers, (float*)p->f, (const float*)p->u,
+                                           (const float*)p->w, (const float*)p->rho, (const float*)p->rhow,
+                                           (const float*)p->adz, (float*)p->flux, (void*)p->stream);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(p->ev1, p->stream));
   p->ran = true;
@@ -327,15 +351,18 @@ int mpdata_plan_sync(mpdata_plan* p) {
   return 0;
 }
 
-int mpdata_plan_download(mpdata_plan* p, double* f, double* flux) {
+static int plan_download(mpdata_plan* p, void* f, void* flux, int eb) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (p->eb != eb) return set_err(MPDATA_ESTATE, "plan precision (%d-byte reals) does not match the call", p->eb);
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_download before upload");
-  if (f) HIP_TRY(hipMemcpyAsync(f, p->f, p->sz.f * 8, hipMemcpyDeviceToHost, p->stream));
+  if (f) HIP_TRY(hipMemcpyAsync(f, p->f, p->sz.f * eb, hipMemcpyDeviceToHost, p->stream));
   if (flux)
-    HIP_TRY(hipMemcpyAsync(flux, p->flux, p->sz.kz * p->ntracers * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(flux, p->flux, p->sz.kz * p->ntracers * eb, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return 0;
 }
+int mpdata_plan_download(mpdata_plan* p, double* f, double* flux) { return plan_download(p, f, flux, 8); }
+int mpdata_plan_download_f32(mpdata_plan* p, float* f, float* flux) { return plan_download(p, f, flux, 4); }
 
 int mpdata_plan_last_kernel_ms(mpdata_plan* p, double* ms) {
   if (!p || !ms) return set_err(MPDATA_EINVAL, "null argument");

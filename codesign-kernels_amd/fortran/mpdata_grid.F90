@@ -6,9 +6,15 @@
 !! the advection routine through host association.  Here they are run-time
 !! values in a module the driver sets before the first call.
 module mpdata_grid
-  use iso_c_binding, only: c_double, c_int, c_int64_t
+  use iso_c_binding, only: c_double, c_float, c_int, c_int64_t
   implicit none
+#ifdef MPDATA_SINGLE
+  !> the reference's precision switch (:12).  Note: the `selected_real_kind(7)` it asks for
+  !! is fp64 on conforming compilers (IEEE single has 6 decimal digits); c_float is fp32.
+  integer, parameter :: rp = c_float
+#else
   integer, parameter :: rp = c_double          !< reference :13, selected_real_kind(13)
+#endif
   integer(c_int64_t) :: nslices = 48            !< CRM instances ("ncrms"), reference :7
   integer(c_int)     :: nz = 58, nx = 32        !< reference :8-9
   integer(c_int)     :: nzm = 57                !< nz-1, reference :14

@@ -18,25 +18,39 @@ module mpdata_hip_mod
   public :: advect_scalar2D, advect_resident_begin, advect_resident_run, advect_resident_end
   public :: mpdata_set_variant, mpdata_check
 
+  ! the C entry points that carry reals exist per precision (include/mpdata_hip.h sections 1-3
+  ! and 6); `make single=1` (-DMPDATA_SINGLE) binds the fp32 ones, rp = c_float
+#ifdef MPDATA_SINGLE
+#define MPDATA_C_ADVECT "mpdata_advect_scalar2d_f32"
+#define MPDATA_C_PLAN_CREATE "mpdata_plan_create_f32"
+#define MPDATA_C_PLAN_UPLOAD "mpdata_plan_upload_f32"
+#define MPDATA_C_PLAN_DOWNLOAD "mpdata_plan_download_f32"
+#else
+#define MPDATA_C_ADVECT "mpdata_advect_scalar2d"
+#define MPDATA_C_PLAN_CREATE "mpdata_plan_create"
+#define MPDATA_C_PLAN_UPLOAD "mpdata_plan_upload"
+#define MPDATA_C_PLAN_DOWNLOAD "mpdata_plan_download"
+#endif
+
   interface
     integer(c_int) function mpdata_advect_scalar2d_c(ncrms, nx, nz, ntracers, f, u, w, rho, rhow, adz, flux) &
-        bind(C, name="mpdata_advect_scalar2d")
-      import :: c_int, c_int64_t, c_double
+        bind(C, name=MPDATA_C_ADVECT)
+      import :: c_int, c_int64_t, rp
       integer(c_int64_t), value :: ncrms
       integer(c_int), value :: nx, nz, ntracers
-      real(c_double) :: f(*), flux(*)
-      real(c_double), intent(in) :: u(*), w(*), rho(*), rhow(*), adz(*)
+      real(rp) :: f(*), flux(*)
+      real(rp), intent(in) :: u(*), w(*), rho(*), rhow(*), adz(*)
     end function
-    integer(c_int) function mpdata_plan_create_c(ncrms, nx, nz, ntracers, plan) bind(C, name="mpdata_plan_create")
+    integer(c_int) function mpdata_plan_create_c(ncrms, nx, nz, ntracers, plan) bind(C, name=MPDATA_C_PLAN_CREATE)
       import :: c_int, c_int64_t, c_ptr
       integer(c_int64_t), value :: ncrms
       integer(c_int), value :: nx, nz, ntracers
       type(c_ptr) :: plan
     end function
-    integer(c_int) function mpdata_plan_upload_c(plan, f, u, w, rho, rhow, adz, flux) bind(C, name="mpdata_plan_upload")
-      import :: c_int, c_ptr, c_double
+    integer(c_int) function mpdata_plan_upload_c(plan, f, u, w, rho, rhow, adz, flux) bind(C, name=MPDATA_C_PLAN_UPLOAD)
+      import :: c_int, c_ptr, rp
       type(c_ptr), value :: plan
-      real(c_double), intent(in) :: f(*), u(*), w(*), rho(*), rhow(*), adz(*), flux(*)
+      real(rp), intent(in) :: f(*), u(*), w(*), rho(*), rhow(*), adz(*), flux(*)
     end function
     integer(c_int) function mpdata_plan_run_c(plan) bind(C, name="mpdata_plan_run")
       import :: c_int, c_ptr
@@ -46,10 +60,10 @@ module mpdata_hip_mod
       import :: c_int, c_ptr
       type(c_ptr), value :: plan
     end function
-    integer(c_int) function mpdata_plan_download_c(plan, f, flux) bind(C, name="mpdata_plan_download")
-      import :: c_int, c_ptr, c_double
+    integer(c_int) function mpdata_plan_download_c(plan, f, flux) bind(C, name=MPDATA_C_PLAN_DOWNLOAD)
+      import :: c_int, c_ptr, rp
       type(c_ptr), value :: plan
-      real(c_double) :: f(*), flux(*)
+      real(rp) :: f(*), flux(*)
     end function
     integer(c_int) function mpdata_plan_last_kernel_ms_c(plan, ms) bind(C, name="mpdata_plan_last_kernel_ms")
       import :: c_int, c_ptr, c_double
@@ -121,7 +135,7 @@ contains
     call mpdata_check(mpdata_plan_sync_c(resident_plan), 'mpdata_plan_sync')
     if (present(kernel_ms)) then
       call mpdata_check(mpdata_plan_last_kernel_ms_c(resident_plan, ms), 'mpdata_plan_last_kernel_ms')
-      kernel_ms = ms
+      kernel_ms = real(ms, rp)
     end if
   end subroutine advect_resident_run
 

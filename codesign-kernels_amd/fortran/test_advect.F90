@@ -83,13 +83,13 @@ contains
     integer(8), parameter :: golden = int(z'9E3779B97F4A7C15', 8), ksid = int(z'D1B54A32D192ED03', 8)
     integer(8), parameter :: m1 = int(z'BF58476D1CE4E5B9', 8), m2 = int(z'94D049BB133111EB', 8)
     integer(8) :: j, z, base
-    real(rp) :: shift
-    shift = 0._rp
+    real(c_double) :: shift   ! the law is defined in fp64; an fp32 build rounds the fp64 value
+    shift = 0._c_double
     if (dist == 1) then
-      if (sid == 2 .or. sid == 3) shift = -0.5_rp
-      if (sid == 0 .or. sid == 4 .or. sid == 5) shift = 0.5_rp
+      if (sid == 2 .or. sid == 3) shift = -0.5_c_double
+      if (sid == 0 .or. sid == 4 .or. sid == 5) shift = 0.5_c_double
     else if (dist == 3) then
-      if (sid == 2 .or. sid == 3) shift = -0.5_rp
+      if (sid == 2 .or. sid == 3) shift = -0.5_c_double
     end if
     base = seed + int(sid, 8) * ksid
     do j = 1, n
@@ -97,7 +97,7 @@ contains
       z = ieor(z, shiftr(z, 30)) * m1
       z = ieor(z, shiftr(z, 27)) * m2
       z = ieor(z, shiftr(z, 31))
-      a(j) = real(shiftr(z, 11), rp) * 2._rp**(-53) + shift
+      a(j) = real(real(shiftr(z, 11), c_double) * 2._c_double**(-53) + shift, rp)
     end do
   end subroutine fill
 

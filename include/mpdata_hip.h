@@ -122,6 +122,14 @@ int mpdata_fill_synthetic_f32_device(float* a, int sid, int64_t rows, int64_t nc
                                      int64_t sl0, int64_t nloc, uint64_t seed, int dist,
                                      void* stream);
 int64_t mpdata_algorithmic_bytes_f32(int64_t ncrms, int nx, int nz, int ntracers);
+/* fp32 plans: create / upload / download have _f32 forms; run, sync, last_kernel_ms and
+ * destroy are the functions of section 3 (a plan remembers its precision; mixing the two
+ * returns MPDATA_ESTATE). */
+int mpdata_plan_create_f32(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan);
+int mpdata_plan_upload_f32(mpdata_plan* plan, const float* f, const float* u, const float* w,
+                           const float* rho, const float* rhow, const float* adz,
+                           const float* flux);
+int mpdata_plan_download_f32(mpdata_plan* plan, float* f, float* flux);
 
 /* ---- 7. Misc. */
 int mpdata_set_variant(int variant);      /* MPDATA_VARIANT_*; returns previous */

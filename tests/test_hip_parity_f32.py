@@ -160,6 +160,15 @@ def test_fp32_host_dropin_call(M, oracle):
     flux = inp["flux"].copy(order="F")
     M.advect_scalar2D_host(f, inp["u"], inp["w"], inp["rho"], inp["rhow"], flux, inp["adz"])
     assert np.array_equal(f, f_ref) and flux_close(flux, flux_ref)
+    plan = M.Plan(150, 32, 28, dtype=F32)
+    plan.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    plan.run()
+    plan.sync()
+    assert plan.last_kernel_ms() > 0
+    f2, flux2 = np.empty_like(f), np.empty_like(flux)
+    plan.download(f2, flux2)
+    plan.close()
+    assert np.array_equal(f2, f_ref) and flux_close(flux2, flux_ref)
     with pytest.raises(M.MpdataError):  # mixed precisions are refused
         M.advect_scalar2D_host(f, inp["u"].astype(np.float64, order="F"), inp["w"], inp["rho"],
                                inp["rhow"], flux, inp["adz"])
