@@ -36,8 +36,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 100 + 100 launches of 0.5 ms.  The first ~30 ms of GPU activity after idle run
+    # 5-10 % slow (clock / power-state ramp, tools/step_series.py), so the warm-up is sized to
+    # leave that transient outside the timed region
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--ncrms-per-gpu", type=int, default=65536)
     ap.add_argument("--nx", type=int, default=32)
     ap.add_argument("--nz", type=int, default=28)
@@ -120,12 +123,20 @@ def make_problem(M, torch, dev, ncrms_loc, ncrms_glob, sl0, nx, nz, ntr, nbuf, d
     return d, fs
 
 
+N_SCRATCH = 3  # f buffers the warm-up launches cycle through (their results are not used)
+
+
 def timed_run(M, torch, dist_mod, world, d, fs, steps, warmup):
+    """fs: min(warmup, N_SCRATCH) scratch buffers for the warm-up launches, followed by one
+    pristine f buffer per timed step (the routine works in place)."""
     def step(f):
         M.advect_scalar2D(f, d["u"], d["w"], d["rho"], d["rhow"], d["flux"], d["adz"])
 
+    nscr = min(warmup, N_SCRATCH)
     for i in range(warmup):
-        step(fs[i])
+        step(fs[i % nscr])
+    fs = fs[nscr:]
+    warmup = 0
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     torch.cuda.synchronize()
     if world > 1:
@@ -182,7 +193,7 @@ def main():
     ntr = args.tracers
     f32 = args.dtype == "f32"
     tdt = torch.float32 if f32 else torch.float64
-    d, fs = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, ntr, steps + warmup, args.dist, tdt)
+    d, fs = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, ntr, steps + min(warmup, N_SCRATCH), args.dist, tdt)
     dt, kms = timed_run(M, torch, dist, world, d, fs, steps, warmup)
     cells_per_step = n_glob * nx * (nz - 1) * ntr
     value = cells_per_step * steps / dt
@@ -225,8 +236,8 @@ def main():
     # ---- side measurement: tracer-batched variant (configs[3]/[4]) -----------
     if not args.no_batched and ntr == 1:
         bt = args.batched_tracers
-        bsteps, bwarm = min(steps, 5), 1
-        d2, fs2 = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, bt, bsteps + bwarm, args.dist, tdt)
+        bsteps, bwarm = min(steps, 5), min(warmup, 2)
+        d2, fs2 = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, bt, bsteps + min(bwarm, N_SCRATCH), args.dist, tdt)
         dt2, kms2 = timed_run(M, torch, dist, world, d2, fs2, bsteps, bwarm)
         if rank == 0:
             ab = M.algorithmic_bytes(n_loc, nx, nz, bt, f32=f32)
@@ -243,7 +254,7 @@ def main():
 
     # ---- side measurement: the same workload in fp32 (reference precision switch) ------
     if not args.no_fp32 and not f32 and ntr == 1:
-        d3, fs3 = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, 1, steps + warmup, args.dist, torch.float32)
+        d3, fs3 = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, 1, steps + min(warmup, N_SCRATCH), args.dist, torch.float32)
         dt3, kms3 = timed_run(M, torch, dist, world, d3, fs3, steps, warmup)
         if rank == 0:
             ab = M.algorithmic_bytes(n_loc, nx, nz, 1, f32=True)

@@ -356,23 +356,27 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   //      one).  LDS image of a column: [array][row][G elements], element (row, sl) stored at
   //      position sl ^ ((row / rows-per-instruction) & (G-1)): the swizzle is applied to the
   //      SOURCE address.
-  const int ni = (nzm + RPI - 1) / RPI;  // DMA instructions per array and column
   constexpr int LPR = T::ROWB / 4;       // lanes (dwords) per row
   constexpr int DPE = RB / 4;            // dwords per element
+  static_assert(T::NIT * T::NWV * RPI == LPS, "the wave's DMA instructions tile the LPS rows of an array block");
   unsigned vdf[T::NIT], vdu[T::NIT], vdw[T::NIT];  // per-lane source byte offsets of the wave's instructions
   int jd[T::NIT];
 #pragma unroll
   for (int it = 0; it < T::NIT; ++it) {
-    const int j = min(wave + it * T::NWV, ni - 1);  // (a clamped duplicate rewrites the same bytes)
+    const int j = wave + it * T::NWV;
     jd[it] = j;
-    const int row = min(j * RPI + lane / LPR, nzm - 1);
+    // rows beyond nzm (the block has LPS of them) have nothing to fetch: an out-of-range
+    // source offset makes the DMA write zeros to that (never read) part of the block
+    // without a memory access, and the wave's instruction count stays fixed
+    const int row = j * RPI + lane / LPR;
+    const bool row_ok = row < nzm;
     const int p = (lane % LPR) / DPE;
     long long sl_d = sl_base + (p ^ (j & (G - 1)));
     if (sl_d >= ncrms) sl_d = ncrms - 1;
     const unsigned part = (lane % DPE) * 4;
-    vdf[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 6) * row) * RB) + part;
-    vdu[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 5) * row) * RB) + part;
-    vdw[it] = (unsigned)((sl_d + ncrms * (long long)(nx + 4) * row) * RB) + part;
+    vdf[it] = row_ok ? (unsigned)((sl_d + ncrms * (long long)(nx + 6) * row) * RB) + part : OOB;
+    vdu[it] = row_ok ? (unsigned)((sl_d + ncrms * (long long)(nx + 5) * row) * RB) + part : OOB;
+    vdw[it] = row_ok ? (unsigned)((sl_d + ncrms * (long long)(nx + 4) * row) * RB) + part : OOB;
   }
   // compute-side read position inside one array block of a slot
   auto lds_pos = [&](int level) __attribute__((always_inline)) {  // position of (level, this instance)

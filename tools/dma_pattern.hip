@@ -93,11 +93,12 @@ template <int G, int DW>
 void run(const double* f, const double* u, const double* w, double* fo, long long ncrms, int nx, int nzm, int persist = 0) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int blocks = persist ? persist : (int)(ncrms / G);
-  hipLaunchKernelGGL((skel<G, DW>), dim3(blocks), dim3(512), 0, 0, f, u, w, fo, ncrms, nx, nzm);
+  for (int r = 0; r < 60; ++r)  // warm-up: the first ~30 ms after idle run 5-10 % slow
+    hipLaunchKernelGGL((skel<G, DW>), dim3(blocks), dim3(512), 0, 0, f, u, w, fo, ncrms, nx, nzm);
   hipEventRecord(e0);
-  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((skel<G, DW>), dim3(blocks), dim3(512), 0, 0, f, u, w, fo, ncrms, nx, nzm);
+  for (int r = 0; r < 60; ++r) hipLaunchKernelGGL((skel<G, DW>), dim3(blocks), dim3(512), 0, 0, f, u, w, fo, ncrms, nx, nzm);
   hipEventRecord(e1); hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 60;
   const double bytes = (double)ncrms * nzm * (nx + 6) * 8.0 * 4;  // 3 reads + 1 write
   printf("blocks %5d G=%2d (%3d-B rows) DMA %2d B/lane: %.3f ms  %.2f TB/s (err %d)\n", blocks, G, G * 8, DW, ms, bytes / (ms * 1e-3) / 1e12, (int)hipGetLastError());
 }

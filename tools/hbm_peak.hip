@@ -23,18 +23,19 @@ int main() {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int grid : {2048, 8192, 65536}) {
     for (int which = 0; which < 3; ++which) {
-      float best = 1e9f;
-      for (int r = 0; r < 6; ++r) {
+      float best = 1e9f, sum = 0; int cnt = 0;
+      for (int r = 0; r < 60; ++r) {
         (void)hipEventRecord(e0);
         if (which == 0) hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, a, b, c, o, n);
         if (which == 1) hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, a, o, n);
         if (which == 2) hipLaunchKernelGGL(k_mix, dim3(grid), dim3(256), 0, 0, a, b, c, o, n);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r >= 20) { sum += ms; ++cnt; }
         if (r > 0 && ms < best) best = ms;
       }
       const double moved = (double)bytes * (which == 0 ? 3 : which == 1 ? 2 : 4);
-      printf("grid %6d %-10s %.3f ms  %.2f TB/s\n", grid, which == 0 ? "read 3R" : which == 1 ? "copy 1R:1W" : "mix 3R:1W", best, moved / (best * 1e-3) / 1e12);
+      printf("grid %6d %-10s best %.3f ms %.2f TB/s   mean(steady) %.3f ms %.2f TB/s\n", grid, which == 0 ? "read 3R" : which == 1 ? "copy 1R:1W" : "mix 3R:1W", best, moved / (best * 1e-3) / 1e12, sum / cnt, moved / (sum / cnt * 1e-3) / 1e12);
     }
   }
   return 0;
