@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="f64: the headline (BASELINE.json fp64); f32: the reference's precision switch")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 side measurement")
+    ap.add_argument("--aligned", action="store_true",
+                    help="allocate f, u, w with equally aligned bases (plain torch.empty) instead of the "
+                         "staggered placement (DESIGN.md 4.4: 8 %% slower at ncrms=65536)")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--dist", type=int, default=1, help="1 conditioned, 2 reference-raw, 3 raw-signed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -107,12 +110,16 @@ def cpu_baseline(nx, nz):
 def make_problem(M, torch, dev, ncrms_loc, ncrms_glob, sl0, nx, nz, ntr, nbuf, dist, dtype=None):
     dtype = torch.float64 if dtype is None else dtype
     sh = M.shapes(ncrms_loc, nx, nz, ntr)
-    d = {k: torch.empty(sh[k], dtype=dtype, device=dev) for k in ("u", "w", "rho", "rhow", "adz", "flux")}
+    # arrays placed as INTEGRATION.md advises a caller to: f, u, w at different offsets modulo
+    # 1 KiB (HBM channel interleave); --aligned reproduces equally aligned bases instead
+    alloc = (lambda shape, k: torch.empty(shape, dtype=dtype, device=dev)) if ALIGNED else \
+            (lambda shape, k: M.empty_staggered(shape, k, dtype, dev))
+    d = {k: alloc(sh[k], k) for k in ("u", "w", "rho", "rhow", "adz", "flux")}
     for k in d:
         M.fill_synthetic(d[k], k, 100, dist, ncrms_global=ncrms_glob, sl0=sl0)
     fs = []
     for b in range(nbuf):
-        f = torch.empty(sh["f"], dtype=dtype, device=dev)
+        f = alloc(sh["f"], "f")
         # per-tracer / per-buffer seeds: distinct data, same law
         if ntr == 1:
             M.fill_synthetic(f, "f", 100 + b, dist, ncrms_global=ncrms_glob, sl0=sl0)
@@ -123,6 +130,7 @@ def make_problem(M, torch, dev, ncrms_loc, ncrms_glob, sl0, nx, nz, ntr, nbuf, d
     return d, fs
 
 
+ALIGNED = False  # --aligned
 N_SCRATCH = 3  # f buffers the warm-up launches cycle through (their results are not used)
 
 
@@ -161,7 +169,9 @@ def timed_run(M, torch, dist_mod, world, d, fs, steps, warmup):
 
 
 def main():
+    global ALIGNED
     args = parse()
+    ALIGNED = args.aligned
     import torch
     import torch.distributed as dist
     import codesign_kernels_amd as M
@@ -224,6 +234,7 @@ def main():
                                    f"tracers={ntr}, device-resident, in-place f",
                        "ncrms_per_gpu": n_loc, "ncrms_global": n_glob, "nx": nx, "nz": nz,
                        "ntracers": ntr, "variant": args.variant, "input_law": args.dist,
+                       "placement": "aligned" if args.aligned else "f,u,w staggered mod 1 KiB",
                        "parallelism": f"ncrms-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

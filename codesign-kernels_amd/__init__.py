@@ -11,12 +11,12 @@ is missing or no device is usable, calls raise.
 """
 from .capi import (MpdataError, Plan, VARIANT_EXACT, VARIANT_FAST, advect_scalar2D,
                    advect_scalar2D_host, algorithmic_bytes, build_library, device_count,
-                   fill_synthetic, get_variant, lib, lib_path, pack_shard, set_tile,
+                   empty_staggered, fill_synthetic, get_variant, lib, lib_path, pack_shard, set_tile,
                    set_variant, shapes, unpack_shard)
 from .shard import gather_outputs, partition, scatter_inputs
 
 __all__ = ["MpdataError", "Plan", "VARIANT_EXACT", "VARIANT_FAST", "advect_scalar2D",
            "advect_scalar2D_host", "algorithmic_bytes", "build_library", "device_count",
-           "fill_synthetic", "get_variant", "lib", "lib_path", "pack_shard", "set_tile",
+           "empty_staggered", "fill_synthetic", "get_variant", "lib", "lib_path", "pack_shard", "set_tile",
            "set_variant", "shapes", "unpack_shard", "partition", "scatter_inputs",
            "gather_outputs"]

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -178,6 +179,34 @@ unsigned grid_for(long long total, int block) {
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// Device buffers the library owns (plans, the host-array calls) come out of one allocation
+// per set, with f, u and w placed at DIFFERENT offsets modulo 1 KiB.  A workgroup reads the
+// same instance range of all three arrays at about the same time; with the three bases
+// equally aligned those requests land on the same HBM channel, and the kernel runs 8 %
+// slower (ncrms = 65536: 0.494 vs 0.458 ms, tools/placement3.py).
+struct Arena {
+  void* base = nullptr;
+  void* p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // f,u,w,rho,rhow,adz,flux
+};
+hipError_t arena_alloc(Arena& a, const size_t bytes[7]) {
+  static const size_t residue[7] = {0, 256, 512, 768, 0, 0, 0};
+  size_t off = 0, offs[7];
+  for (int i = 0; i < 7; ++i) {
+    off = (off + 1023) / 1024 * 1024 + residue[i];
+    offs[i] = off;
+    off += bytes[i];
+  }
+  hipError_t e = hipMalloc(&a.base, off + 1024);
+  if (e != hipSuccess) { a.base = nullptr; return e; }
+  const uintptr_t b0 = ((uintptr_t)a.base + 1023) / 1024 * 1024;
+  for (int i = 0; i < 7; ++i) a.p[i] = (void*)(b0 + offs[i]);
+  return hipSuccess;
+}
+void arena_free(Arena& a) {
+  if (a.base) (void)hipFree(a.base);
+  a = Arena();
+}
+
 template <typename R>
 int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u, const R* w,
                   const R* rho, const R* rhow, const R* adz, R* flux, void* stream) {
@@ -235,7 +264,8 @@ struct mpdata_plan {
   int nx, nz, ntracers;
   int eb;  // bytes per real: 8 (fp64 plan) or 4 (fp32 plan)
   Sizes sz;
-  void *f, *u, *w, *rho, *rhow, *adz, *flux;
+  Arena arena;
+  void *f, *u, *w, *rho, *rhow, *adz, *flux;  // = arena.p[0..6]
   hipStream_t stream;
   hipEvent_t ev0, ev1;
   bool uploaded, ran;
@@ -269,14 +299,13 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   if (!p) return set_err(MPDATA_EINVAL, "out of host memory");
   p->ncrms = ncrms; p->nx = nx; p->nz = nz; p->ntracers = ntracers; p->eb = eb;
   p->sz = sizes_of(ncrms, nx, nz, ntracers);
-  hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = hipMalloc(&p->f, p->sz.f * eb);
-  if (e == hipSuccess) e = hipMalloc(&p->u, p->sz.u * eb);
-  if (e == hipSuccess) e = hipMalloc(&p->w, p->sz.w * eb);
-  if (e == hipSuccess) e = hipMalloc(&p->rho, p->sz.k * eb);
-  if (e == hipSuccess) e = hipMalloc(&p->rhow, p->sz.kz * eb);
-  if (e == hipSuccess) e = hipMalloc(&p->adz, p->sz.k * eb);
-  if (e == hipSuccess) e = hipMalloc(&p->flux, p->sz.kz * ntracers * eb);
+  const size_t nb[7] = {p->sz.f * eb, p->sz.u * eb, p->sz.w * eb, p->sz.k * eb, p->sz.kz * eb, p->sz.k * eb,
+                        p->sz.kz * ntracers * eb};
+  hipError_t e = arena_alloc(p->arena, nb);
+  if (e == hipSuccess) {
+    p->f = p->arena.p[0]; p->u = p->arena.p[1]; p->w = p->arena.p[2]; p->rho = p->arena.p[3];
+    p->rhow = p->arena.p[4]; p->adz = p->arena.p[5]; p->flux = p->arena.p[6];
+  }
   if (e == hipSuccess) e = hipStreamCreate(&p->stream);
   if (e == hipSuccess) e = hipEventCreate(&p->ev0);
   if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -376,13 +405,7 @@ int mpdata_plan_last_kernel_ms(mpdata_plan* p, double* ms) {
 
 int mpdata_plan_destroy(mpdata_plan* p) {
   if (!p) return 0;
-  if (p->f) (void)hipFree(p->f);
-  if (p->u) (void)hipFree(p->u);
-  if (p->w) (void)hipFree(p->w);
-  if (p->rho) (void)hipFree(p->rho);
-  if (p->rhow) (void)hipFree(p->rhow);
-  if (p->adz) (void)hipFree(p->adz);
-  if (p->flux) (void)hipFree(p->flux);
+  arena_free(p->arena);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -398,17 +421,12 @@ int mpdata_plan_destroy(mpdata_plan* p) {
 // time in exactly these copies, results/advect.pgiacc.17.7-nvprof:18-19).
 namespace {
 struct ChunkBufs {
+  Arena arena;
   double *f = nullptr, *u = nullptr, *w = nullptr, *rho = nullptr, *rhow = nullptr, *adz = nullptr, *flux = nullptr;
   hipStream_t stream = nullptr;
 };
 void free_chunk(ChunkBufs& b) {
-  if (b.f) (void)hipFree(b.f);
-  if (b.u) (void)hipFree(b.u);
-  if (b.w) (void)hipFree(b.w);
-  if (b.rho) (void)hipFree(b.rho);
-  if (b.rhow) (void)hipFree(b.rhow);
-  if (b.adz) (void)hipFree(b.adz);
-  if (b.flux) (void)hipFree(b.flux);
+  arena_free(b.arena);
   if (b.stream) (void)hipStreamDestroy(b.stream);
   b = ChunkBufs();
 }
@@ -442,13 +460,14 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
   hipError_t e = hipSuccess;
   for (int i = 0; i < nsets && e == hipSuccess; ++i) {
     ChunkBufs& b = set[i];
-    if (e == hipSuccess) e = hipMalloc((void**)&b.f, rows_f * C * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&b.u, rows_u * C * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&b.w, rows_w * C * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&b.rho, rows_k * C * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&b.rhow, rows_kz * C * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&b.adz, rows_k * C * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&b.flux, rows_x * C * 8);
+    const size_t nb[7] = {rows_f * C * 8, rows_u * C * 8, rows_w * C * 8, rows_k * C * 8, rows_kz * C * 8,
+                          rows_k * C * 8, rows_x * C * 8};
+    if (e == hipSuccess) e = arena_alloc(b.arena, nb);
+    if (e == hipSuccess) {
+      b.f = (double*)b.arena.p[0]; b.u = (double*)b.arena.p[1]; b.w = (double*)b.arena.p[2];
+      b.rho = (double*)b.arena.p[3]; b.rhow = (double*)b.arena.p[4]; b.adz = (double*)b.arena.p[5];
+      b.flux = (double*)b.arena.p[6];
+    }
     if (e == hipSuccess) e = hipStreamCreate(&b.stream);
   }
   const size_t hp = (size_t)ncrms * 8;  // host pitch: one row of all instances
@@ -509,16 +528,17 @@ int mpdata_advect_scalar2d_f32(int64_t ncrms, int nx, int nz, int ntracers, floa
   const size_t n[7] = {sz.f, sz.u, sz.w, sz.k, sz.kz, sz.k, sz.kz * (size_t)ntracers};
   const float* h[7] = {f, u, w, rho, rhow, adz, flux};
   float* d[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipError_t e = hipSuccess;
-  for (int i = 0; i < 7 && e == hipSuccess; ++i) e = hipMalloc((void**)&d[i], n[i] * 4);
+  Arena arena;
+  const size_t nb[7] = {n[0] * 4, n[1] * 4, n[2] * 4, n[3] * 4, n[4] * 4, n[5] * 4, n[6] * 4};
+  hipError_t e = arena_alloc(arena, nb);
+  for (int i = 0; i < 7 && e == hipSuccess; ++i) d[i] = (float*)arena.p[i];
   for (int i = 0; i < 7 && e == hipSuccess; ++i) e = hipMemcpy(d[i], h[i], n[i] * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     rc = mpdata_advect_scalar2d_f32_device(ncrms, nx, nz, ntracers, d[0], d[1], d[2], d[3], d[4], d[5], d[6], nullptr);
     if (rc == 0) e = hipMemcpy(f, d[0], n[0] * 4, hipMemcpyDeviceToHost);
     if (rc == 0 && e == hipSuccess) e = hipMemcpy(flux, d[6], n[6] * 4, hipMemcpyDeviceToHost);
   }
-  for (int i = 0; i < 7; ++i)
-    if (d[i]) (void)hipFree(d[i]);
+  arena_free(arena);
   if (rc) return rc;
   if (e != hipSuccess) return hip_err(e, "mpdata_advect_scalar2d_f32");
   return 0;
