@@ -102,17 +102,27 @@ void run(const double* f, const double* u, const double* w, double* fo, long lon
   const double bytes = (double)ncrms * nzm * (nx + 6) * 8.0 * 4;  // 3 reads + 1 write
   printf("blocks %5d G=%2d (%3d-B rows) DMA %2d B/lane: %.3f ms  %.2f TB/s (err %d)\n", blocks, G, G * 8, DW, ms, bytes / (ms * 1e-3) / 1e12, (int)hipGetLastError());
 }
-int main() {
+int main(int argc, char** argv) {
+  // argv[1] = 1: stagger the arrays by 256 B each (different offsets modulo 1 KiB)
+  const size_t stag = argc > 1 && argv[1][0] == '1' ? 256 : 0;
   const long long ncrms = 65536; const int nx = 32, nzm = 27;
   size_t n = ncrms * (nx + 6) * nzm;
   double *f, *u, *w, *fo;
-  hipMalloc(&f, n * 8); hipMalloc(&u, n * 8); hipMalloc(&w, n * 8); hipMalloc(&fo, n * 8);
+  char *rf, *ru, *rw, *ro;
+  hipMalloc(&rf, n * 8 + 4096); hipMalloc(&ru, n * 8 + 4096); hipMalloc(&rw, n * 8 + 4096); hipMalloc(&ro, n * 8 + 4096);
+  f = (double*)rf; u = (double*)(ru + stag); w = (double*)(rw + 2 * stag); fo = (double*)(ro + 3 * stag);
+  printf("stagger %zu B\n", stag);
   hipMemset(f, 0, n * 8); hipMemset(u, 0, n * 8); hipMemset(w, 0, n * 8);
-  for (int rep = 0; rep < 2; ++rep) {
+  for (int rep = 0; rep < 1; ++rep) {
     run<16, 4>(f, u, w, fo, ncrms, nx, nzm);
     run<16, 16>(f, u, w, fo, ncrms, nx, nzm);
     run<32, 4>(f, u, w, fo, ncrms, nx, nzm);
     run<32, 16>(f, u, w, fo, ncrms, nx, nzm);
+    printf("in place (stores go back into f):\n");
+    run<16, 4>(f, u, w, f, ncrms, nx, nzm);
+    run<32, 4>(f, u, w, f, ncrms, nx, nzm);
+    run<32, 16>(f, u, w, f, ncrms, nx, nzm);
+    printf("persistent:\n");
     run<16, 4>(f, u, w, fo, ncrms, nx, nzm, 512);
     run<16, 4>(f, u, w, fo, ncrms, nx, nzm, 1024);
     run<32, 16>(f, u, w, fo, ncrms, nx, nzm, 256);

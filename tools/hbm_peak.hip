@@ -15,10 +15,15 @@ __global__ void __launch_bounds__(256) k_copy(const d2* a, d2* o, size_t n) {
 __global__ void __launch_bounds__(256) k_mix(const d2* a, const d2* b, const d2* c, d2* o, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = a[i] + b[i] + c[i];
 }
-int main() {
+int main(int argc, char** argv) {
+  // argv[1] = 1: stagger the four arrays by 256 B each (different offsets modulo 1 KiB)
+  const size_t stag = argc > 1 && argv[1][0] == '1' ? 256 : 0;
   const size_t bytes = 65536ull * 38 * 27 * 8, n = bytes / 16;
   d2 *a, *b, *c, *o;
-  (void)hipMalloc(&a, bytes); (void)hipMalloc(&b, bytes); (void)hipMalloc(&c, bytes); (void)hipMalloc(&o, bytes);
+  char *ra, *rb, *rc, *ro;
+  (void)hipMalloc(&ra, bytes + 4096); (void)hipMalloc(&rb, bytes + 4096); (void)hipMalloc(&rc, bytes + 4096); (void)hipMalloc(&ro, bytes + 4096);
+  a = (d2*)ra; b = (d2*)(rb + stag); c = (d2*)(rc + 2 * stag); o = (d2*)(ro + 3 * stag);
+  printf("stagger %zu B\n", stag);
   (void)hipMemset(a, 0, bytes); (void)hipMemset(b, 0, bytes); (void)hipMemset(c, 0, bytes); (void)hipMemset(o, 0, bytes);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int grid : {2048, 8192, 65536}) {
