@@ -10,13 +10,13 @@ torch.distributed plumbing.  There is no CPU fallback here: if the HIP library
 is missing or no device is usable, calls raise.
 """
 from .capi import (MpdataError, Plan, VARIANT_EXACT, VARIANT_FAST, advect_scalar2D,
-                   advect_scalar2D_host, algorithmic_bytes, build_library, device_count,
+                   advect_scalar2D_host, algorithmic_bytes, build_library, debug_stages, device_count,
                    empty_staggered, fill_synthetic, get_variant, lib, lib_path, pack_shard, set_tile,
-                   set_variant, shapes, unpack_shard)
+                   set_variant, shapes, stage_shapes, unpack_shard)
 from .shard import gather_outputs, partition, scatter_inputs
 
 __all__ = ["MpdataError", "Plan", "VARIANT_EXACT", "VARIANT_FAST", "advect_scalar2D",
-           "advect_scalar2D_host", "algorithmic_bytes", "build_library", "device_count",
+           "advect_scalar2D_host", "algorithmic_bytes", "build_library", "debug_stages", "device_count",
            "empty_staggered", "fill_synthetic", "get_variant", "lib", "lib_path", "pack_shard", "set_tile",
-           "set_variant", "shapes", "unpack_shard", "partition", "scatter_inputs",
+           "set_variant", "shapes", "stage_shapes", "unpack_shard", "partition", "scatter_inputs",
            "gather_outputs"]

@@ -90,6 +90,8 @@ def lib():
         L.mpdata_plan_upload_f32.argtypes = [vp] + [dp] * 7
         L.mpdata_plan_download_f32.restype = ci
         L.mpdata_plan_download_f32.argtypes = [vp, dp, dp]
+        L.mpdata_debug_stages_device.restype = ci
+        L.mpdata_debug_stages_device.argtypes = [i64, ci, ci, ci] + [dp] * 11 + [vp]
         L.mpdata_set_variant.restype = ci
         L.mpdata_set_variant.argtypes = [ci]
         L.mpdata_get_variant.restype = ci
@@ -206,6 +208,29 @@ def advect_scalar2D(f, u, w, rho, rhow, flux, adz, stream=None):
             (("f", f), ("u", u), ("w", w), ("rho", rho), ("rhow", rhow), ("adz", adz), ("flux", flux))]
     fn = lib().mpdata_advect_scalar2d_device if f.dtype == torch.float64 else lib().mpdata_advect_scalar2d_f32_device
     _check(fn(ncrms, nx, nz, nt, *ptrs, _stream_handle(stream)))
+
+
+def stage_shapes(ncrms, nx, nz):
+    """torch-side shapes of the reference's temporaries (reference :485-491)."""
+    nzm = nz - 1
+    return {"uuu": (nzm, nx + 5, ncrms), "www": (nz, nx + 4, ncrms), "mx": (nzm, nx + 2, ncrms),
+            "mn": (nzm, nx + 2, ncrms)}
+
+
+def debug_stages(f, u, w, rho, rhow, flux, adz, tmp, last_stage, stream=None):
+    """Stage-by-stage debug mode (include/mpdata_hip.h section 7): run stages 1..last_stage
+    unfused; `tmp` = dict of float64 device tensors uuu, www, mx, mn (stage_shapes)."""
+    import torch
+    ncrms, nx, nz, nt = _dims_from(f, u)
+    if nt != 1:
+        raise MpdataError(-1, "debug_stages: one tracer")
+    sh = shapes(ncrms, nx, nz, 1)
+    ptrs = [_dev_ptr(t, sh[k], k, torch.float64) for k, t in
+            (("f", f), ("u", u), ("w", w), ("rho", rho), ("rhow", rhow), ("adz", adz), ("flux", flux))]
+    ssh = stage_shapes(ncrms, nx, nz)
+    tptrs = [_dev_ptr(tmp[k], ssh[k], k, torch.float64) for k in ("uuu", "www", "mx", "mn")]
+    _check(lib().mpdata_debug_stages_device(ncrms, nx, nz, int(last_stage), *ptrs, *tptrs,
+                                            _stream_handle(stream)))
 
 
 def _host_ptr(a, name, writable=False, dtype=np.float64):

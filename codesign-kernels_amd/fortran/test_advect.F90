@@ -1,16 +1,20 @@
 !> Driver of the MI355X build: the role of the reference's `program test_advect`
 !! (mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:3-68, :645-683).
 !!
-!!   ./advect [ncrms nx nz [dist [variant [dumpfile]]]]
+!!   ./advect [ncrms nx nz [dist [variant [dumpfile [reffile]]]]]
 !!
-!! Sequence (reference :48-50): init() -> advect_scalar2D(f,u,w,rho,rhow,flux)
-!! -> save().  Sizes are run-time (the reference fixes them at compile time,
+!! Sequence (reference :48-58): init() -> advect_scalar2D(f,u,w,rho,rhow,flux)
+!! -> save() -> compare().  Sizes are run-time (the reference fixes them at compile time,
 !! :7-9); inputs come from a portable seeded generator instead of the
 !! compiler's random_number (:649-660), in the same fill order.  Timing lines
 !! keep the reference's format (:640, :239).  The reference's compare() step
 !! (:679-683) needs the CPU routine's result; this program does not contain a
-!! CPU advection routine -- tests/test_fortran_driver.py runs it, reads the
-!! dump written by save() and makes that comparison against the oracle.
+!! CPU advection routine.  Instead compare() takes the trusted result from
+!! `reffile` (stream binary, f then flux -- the format save() writes, and the
+!! format the reference executable built by oracle/build_ref.py dumps) and
+!! prints the reference's two "Relative L1 Error" lines (:681-682);
+!! tests/test_fortran_driver.py feeds it the oracle's result.  `dumpfile` / `reffile`
+!! may be `-` to skip.
 program test_advect
   use iso_c_binding
   use mpdata_grid
@@ -21,11 +25,11 @@ program test_advect
   real(rp), allocatable :: f_in(:,:,:,:,:)
   integer(c_int64_t) :: n_arg
   integer :: nx_arg, nz_arg, dist, variant, rc
-  character(len=512) :: arg, dumpfile
+  character(len=512) :: arg, dumpfile, reffile
   integer(8) :: t1, t2, tr
   real(rp) :: kms
 
-  n_arg = 64; nx_arg = 32; nz_arg = 28; dist = 1; variant = 0; dumpfile = ''
+  n_arg = 64; nx_arg = 32; nz_arg = 28; dist = 1; variant = 0; dumpfile = ''; reffile = ''
   if (command_argument_count() >= 3) then
     call get_command_argument(1, arg); read(arg, *) n_arg
     call get_command_argument(2, arg); read(arg, *) nx_arg
@@ -38,6 +42,9 @@ program test_advect
     call get_command_argument(5, arg); read(arg, *) variant
   end if
   if (command_argument_count() >= 6) call get_command_argument(6, dumpfile)
+  if (command_argument_count() >= 7) call get_command_argument(7, reffile)
+  if (trim(dumpfile) == '-') dumpfile = ''
+  if (trim(reffile) == '-') reffile = ''
 
   call grid_set(n_arg, nx_arg, nz_arg)
   allocate(f(nslices, -2:nx+3, 1, nzm, 1), u(nslices, -1:nx+3, 1, nzm), w(nslices, -1:nx+2, 1, nz))
@@ -52,6 +59,7 @@ program test_advect
   call system_clock(t2, tr)
   write(*,*) 'HIP Timing (call, transfers included): ', dble(t2-t1)/dble(tr)
   call save()
+  call compare()
 
   ! ---- device-resident: the reference's timed region (kernels only, :110-:238)
   call init()
@@ -123,5 +131,21 @@ contains
     write(iu) flux
     close(iu)
   end subroutine save
+
+  !> reference :679-683, with the trusted result read from `reffile` instead of kept
+  !! from an in-program CPU call
+  subroutine compare()
+    real(rp), allocatable :: f_save(:,:,:,:,:), flux_save(:,:,:)
+    integer :: iu
+    if (len_trim(reffile) == 0) return
+    allocate(f_save, mold=f)
+    allocate(flux_save, mold=flux)
+    open(newunit=iu, file=trim(reffile), access='stream', form='unformatted', status='old')
+    read(iu) f_save
+    read(iu) flux_save
+    close(iu)
+    write(*,*) 'Relative L1 Error - f    : ' , sum(abs( f    - f_save    )) / sum(abs( f_save    ))
+    write(*,*) 'Relative L1 Error - flux : ' , sum(abs( flux - flux_save )) / sum(abs( flux_save ))
+  end subroutine compare
 
 end program test_advect

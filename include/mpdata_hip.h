@@ -131,7 +131,24 @@ int mpdata_plan_upload_f32(mpdata_plan* plan, const float* f, const float* u, co
                            const float* flux);
 int mpdata_plan_download_f32(mpdata_plan* plan, float* f, float* flux);
 
-/* ---- 7. Misc. */
+/* ---- 7. Stage-by-stage debug mode (not a fast path).  The same routine as eight unfused
+ * kernels, one per stage of the reference -- the split its OpenACC version makes, reference
+ * :112-235 -- that materialise the reference's temporaries (:485-491) in caller-provided
+ * device arrays uuu(ncrms,-1:nx+3,nzm), www(ncrms,-1:nx+2,nz), mx/mn(ncrms,0:nx+1,nzm), and
+ * stop after stage `last_stage`:
+ *   1 extrema of the incoming field (:513-526)   2 upwind fluxes + flux sum (:528-548)
+ *   3 first-pass update (:550-560)               4 antidiffusive fluxes (:561-586)
+ *   5 extrema of the first-pass field (:588-600) 6 limiter ratios (:601-612)
+ *   7 limited fluxes, flux += (:613-627)         8 final update (:630-637)
+ * Every array is then what the reference holds at that point, bit for bit (no FMA
+ * contraction, reference expression and summation order), so a parity failure of the fused
+ * kernels can be localised to a stage.  fp64, one tracer. */
+int mpdata_debug_stages_device(int64_t ncrms, int nx, int nz, int last_stage, double* f,
+                               const double* u, const double* w, const double* rho,
+                               const double* rhow, const double* adz, double* flux,
+                               double* uuu, double* www, double* mx, double* mn, void* stream);
+
+/* ---- 8. Misc. */
 int mpdata_set_variant(int variant);      /* MPDATA_VARIANT_*; returns previous */
 int mpdata_get_variant(void);
 int mpdata_set_tile(int tile);            /* kernel tiling id; -1 = default */

@@ -104,7 +104,7 @@ static void scratch_free(scratch_t *s) {
  */
 static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *u,
                          const real *w, const real *rho, const real *rhow,
-                         const real *adz, real *flux, scratch_t sc) {
+                         const real *adz, real *flux, scratch_t sc, int last_stage) {
   real *mx = sc.mx, *mn = sc.mn, *uuu = sc.uuu, *www = sc.www;
   real *iadz = sc.iadz, *irho = sc.irho, *irhow = sc.irhow;
   const int nx = d.nx, nz = d.nz, nzm = d.nzm;
@@ -131,6 +131,7 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
       }
   }
 
+  if (last_stage < 2) return;  /* stage-by-stage mode, see mpdata_oracle_advect_stages */
   /* :528-548  upwind fluxes and their horizontal sum */
   for (k = 1; k <= nzm; k++) {
     kb = k - 1 > 1 ? k - 1 : 1;
@@ -145,6 +146,7 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
       for (sl = s0; sl < s1; sl++) K2_(flux, sl, k) = K2_(flux, sl, k) + WWW_(sl, i, k);
   }
 
+  if (last_stage < 3) return;  /* stage-by-stage mode, see mpdata_oracle_advect_stages */
   /* :550-560  first-pass update, halo columns -1..nx+2 included */
   for (k = 1; k <= nzm; k++) {
     for (sl = s0; sl < s1; sl++) {
@@ -157,6 +159,7 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
                                        (WWW_(sl, i, k + 1) - WWW_(sl, i, k)) * K2_(iadz, sl, k)) * K2_(irho, sl, k);
   }
 
+  if (last_stage < 4) return;  /* stage-by-stage mode, see mpdata_oracle_advect_stages */
   /* :561-586  antidiffusive fluxes */
   for (k = 1; k <= nzm; k++) {
     kc = k + 1 < nzm ? k + 1 : nzm;
@@ -186,6 +189,7 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
   for (i = -1; i <= nxp2; i++)
     for (sl = s0; sl < s1; sl++) WWW_(sl, i, 1) = R_(0.0);
 
+  if (last_stage < 5) return;  /* stage-by-stage mode, see mpdata_oracle_advect_stages */
   /* :588-600  pass-1 extrema */
   for (k = 1; k <= nzm; k++) {
     kc = k + 1 < nzm ? k + 1 : nzm;
@@ -197,6 +201,7 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
         MN_(sl, i, k) = dmin(dmin(dmin(dmin(dmin(F_(sl, ib, k), F_(sl, ic, k)), F_(sl, i, kb)), F_(sl, i, kc)), F_(sl, i, k)), MN_(sl, i, k));
       }
   }
+  if (last_stage < 6) return;  /* stage-by-stage mode, see mpdata_oracle_advect_stages */
   /* :601-612  limiter normalisation (note kc clamps at nzm, :602) */
   for (k = 1; k <= nzm; k++) {
     kc = k + 1 < nzm ? k + 1 : nzm;
@@ -211,6 +216,7 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
                          K2_(iadz, sl, k) * (pp(WWW_(sl, i, kc)) + pn(WWW_(sl, i, k))) + eps);
       }
   }
+  if (last_stage < 7) return;  /* stage-by-stage mode, see mpdata_oracle_advect_stages */
   /* :613-627  flux limiting; flux gets the limited vertical flux added */
   for (k = 1; k <= nzm; k++) {
     kb = k - 1 > 1 ? k - 1 : 1;
@@ -228,6 +234,7 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
       }
   }
 
+  if (last_stage < 8) return;  /* stage-by-stage mode, see mpdata_oracle_advect_stages */
   /* :630-637  final positive-definite update of the interior */
   for (k = 1; k <= nzm; k++)
     for (i = 1; i <= nx; i++)
@@ -252,7 +259,7 @@ int SYM(mpdata_oracle_advect)(int64_t ncrms, int nx, int nz, real *f, const real
   d.n = ncrms; d.nx = nx; d.nz = nz; d.nzm = nz - 1;
   if (scratch_alloc(&sc, d) != 0) { scratch_free(&sc); return -1; }
   if (nthreads <= 1) {
-    advect_range(d, 0, ncrms, f, u, w, rho, rhow, adz, flux, sc);
+    advect_range(d, 0, ncrms, f, u, w, rho, rhow, adz, flux, sc, 8);
   } else {
     const int64_t chunk = 64;
     const int64_t nchunks = (ncrms + chunk - 1) / chunk;
@@ -262,10 +269,38 @@ int SYM(mpdata_oracle_advect)(int64_t ncrms, int nx, int nz, real *f, const real
 #endif
     for (c = 0; c < nchunks; c++) {
       int64_t s0 = c * chunk, s1 = s0 + chunk < ncrms ? s0 + chunk : ncrms;
-      advect_range(d, s0, s1, f, u, w, rho, rhow, adz, flux, sc);
+      advect_range(d, s0, s1, f, u, w, rho, rhow, adz, flux, sc, 8);
     }
   }
   scratch_free(&sc);
+  return 0;
+}
+
+/*
+ * Stage-by-stage mode (the counterpart of the product's mpdata_debug_stages_device): the
+ * routine stopped after stage `last_stage` = 1..8 --
+ *   1 extrema of the incoming field (:513-526)   2 upwind fluxes + flux sum (:528-548)
+ *   3 first-pass update (:550-560)               4 antidiffusive fluxes (:561-586)
+ *   5 extrema of the first-pass field (:588-600) 6 limiter ratios (:601-612)
+ *   7 limited fluxes, flux += (:613-627)         8 final update (:630-637)
+ * -- with the reference's temporaries (:485-491) in caller-provided arrays
+ * uuu(ncrms,-1:nx+3,nzm), www(ncrms,-1:nx+2,nz), mx/mn(ncrms,0:nx+1,nzm).
+ */
+int SYM(mpdata_oracle_advect_stages)(int64_t ncrms, int nx, int nz, int last_stage, real *f,
+                                     const real *u, const real *w, const real *rho, const real *rhow,
+                                     const real *adz, real *flux, real *uuu, real *www, real *mx,
+                                     real *mn) {
+  dims_t d;
+  scratch_t sc;
+  if (ncrms < 1 || nx < 1 || nz < 3 || last_stage < 1 || last_stage > 8) return -1;
+  d.n = ncrms; d.nx = nx; d.nz = nz; d.nzm = nz - 1;
+  sc.mx = mx; sc.mn = mn; sc.uuu = uuu; sc.www = www;
+  sc.iadz = (real *)malloc((size_t)ncrms * d.nzm * sizeof(real));
+  sc.irho = (real *)malloc((size_t)ncrms * d.nzm * sizeof(real));
+  sc.irhow = (real *)malloc((size_t)ncrms * d.nzm * sizeof(real));
+  if (!sc.iadz || !sc.irho || !sc.irhow) { free(sc.iadz); free(sc.irho); free(sc.irhow); return -1; }
+  advect_range(d, 0, ncrms, f, u, w, rho, rhow, adz, flux, sc, last_stage);
+  free(sc.iadz); free(sc.irho); free(sc.irhow);
   return 0;
 }
 

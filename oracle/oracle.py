@@ -65,6 +65,8 @@ def lib():
         L.mpdata_oracle_fill.argtypes = [dp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64,
                                          ctypes.c_int]
+        L.mpdata_oracle_advect_stages.restype = ctypes.c_int
+        L.mpdata_oracle_advect_stages.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [dp] * 11
         fp = ctypes.POINTER(ctypes.c_float)
         L.mpdata_oracle_advect_f32.restype = ctypes.c_int
         L.mpdata_oracle_advect_f32.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int,
@@ -171,6 +173,30 @@ def advect(inp, nthreads=1):
     if rc != 0:
         raise RuntimeError(f"mpdata_oracle_advect failed rc={rc}")
     return f, flux
+
+
+def stage_shapes(ncrms, nx, nz):
+    """Fortran-order shapes of the reference's temporaries (reference :485-491)."""
+    nzm = nz - 1
+    return {"uuu": (ncrms, nx + 5, nzm), "www": (ncrms, nx + 4, nz), "mx": (ncrms, nx + 2, nzm),
+            "mn": (ncrms, nx + 2, nzm)}
+
+
+def advect_stages(inp, last_stage, fill=0.0):
+    """The routine stopped after stage `last_stage` (1..8, see mpdata_oracle_advect_stages);
+    returns a dict with f, flux and the temporaries uuu, www, mx, mn (fp64 only).  The
+    temporaries start as `fill` (parts of them are never written, as in the reference)."""
+    f = np.array(inp["f"], order="F", copy=True)
+    flux = np.array(inp["flux"], order="F", copy=True)
+    ncrms, nxp6, nzm = f.shape
+    nx, nz = nxp6 - 6, nzm + 1
+    tmp = {k: np.full(s, fill, dtype=np.float64, order="F") for k, s in stage_shapes(ncrms, nx, nz).items()}
+    rc = lib().mpdata_oracle_advect_stages(ncrms, nx, nz, last_stage, _dp(f), _dp(inp["u"]), _dp(inp["w"]),
+                                           _dp(inp["rho"]), _dp(inp["rhow"]), _dp(inp["adz"]), _dp(flux),
+                                           _dp(tmp["uuu"]), _dp(tmp["www"]), _dp(tmp["mx"]), _dp(tmp["mn"]))
+    if rc != 0:
+        raise RuntimeError(f"mpdata_oracle_advect_stages failed rc={rc}")
+    return {"f": f, "flux": flux, **tmp}
 
 
 def max_threads():

@@ -38,12 +38,23 @@ def test_driver_matches_oracle(oracle, tmp_path, shape, dist, variant):
     assert os.path.exists(EXE), "Fortran driver not built"
     ncrms, nx, nz = shape
     dump = tmp_path / "out.bin"
-    res = subprocess.run([EXE, str(ncrms), str(nx), str(nz), str(dist), str(variant), str(dump)],
+    inp = oracle.make_inputs(ncrms, nx, nz, seed=100, dist=dist)   # the driver's init(): seed 100
+    f_ref, flux_ref = oracle.advect(inp)
+    ref = tmp_path / "ref.bin"                                     # what compare() reads
+    with open(ref, "wb") as fh:
+        fh.write(f_ref.tobytes(order="F"))
+        fh.write(flux_ref.tobytes(order="F"))
+    res = subprocess.run([EXE, str(ncrms), str(nx), str(nz), str(dist), str(variant), str(dump), str(ref)],
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "HIP Timing:" in res.stdout
-    inp = oracle.make_inputs(ncrms, nx, nz, seed=100, dist=dist)   # the driver's init(): seed 100
-    f_ref, flux_ref = oracle.advect(inp)
+    # the reference's compare() lines (:681-682), printed by the driver itself
+    import re
+    m = re.search(r"Relative L1 Error - f\s*:\s*([0-9.Ee+-]+)", res.stdout)
+    m2 = re.search(r"Relative L1 Error - flux\s*:\s*([0-9.Ee+-]+)", res.stdout)
+    assert m and m2, res.stdout
+    assert float(m.group(1)) == (0.0 if variant == 0 else pytest.approx(0.0, abs=1e-14))
+    assert float(m2.group(1)) < 1e-13
     raw = np.fromfile(dump, dtype=np.float64)
     f = raw[:f_ref.size].reshape(f_ref.shape, order="F")
     flux = raw[f_ref.size:].reshape(flux_ref.shape, order="F")
