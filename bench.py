@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="f64: the headline (BASELINE.json fp64); f32: the reference's precision switch")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 side measurement")
+    ap.add_argument("--no-bwk", action="store_true", help="skip the biharmonic_wk_scalar side measurement")
     ap.add_argument("--aligned", action="store_true",
                     help="allocate f, u, w with equally aligned bases (plain torch.empty) instead of the "
                          "staggered placement (DESIGN.md 4.4: 8 %% slower at ncrms=65536)")
@@ -104,6 +105,56 @@ def cpu_baseline(nx, nz):
                "sample": f"C restatement (gcc -O3 -ffp-contract=off), ncrms={ncrms}, best of 3"}
     out["port_serial"] = port1
     out["port_openmp"] = {"value": portn, "cores": nthr}
+    return out
+
+
+def bench_bwk(torch, dev, steps, warmup, with_cpu):
+    """Side measurement of the second kernel: biharmonic_wk_scalar on a
+    cubed-sphere ne=30 mesh (5400 elements x 72 levels x 40 tracers, 2 GB of qtens), FAST
+    variant, in place on resident data (random values; the arithmetic is data-independent)."""
+    import codesign_kernels_amd.bwk as K
+    nelemd, nlev, qsize = 5400, 72, 40
+    K.set_variant(K.VARIANT_FAST)
+    g = torch.Generator(device=dev).manual_seed(11)
+    q = torch.rand((nelemd, qsize, nlev, 4, 4), dtype=torch.float64, device=dev, generator=g)
+    el = torch.rand((nelemd, 144), dtype=torch.float64, device=dev, generator=g)
+    dv = torch.rand((4, 4), dtype=torch.float64, device=dev, generator=g)
+    for _ in range(warmup):
+        K.biharmonic_wk_scalar(el, q, dv)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        K.biharmonic_wk_scalar(el, q, dv)   # rrearth ~ 1e-7 twice per call: the field decays, stays finite
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms = e0.elapsed_time(e1) / steps
+    ab = K.algorithmic_bytes(nelemd, nlev, qsize)
+    slabs = nelemd * nlev * qsize
+    out = {"workload": f"atmosphere/biharmonic_wk_kernel.F90 biharmonic_wk_scalar: nelemd={nelemd} nlev={nlev} "
+                       f"qsize={qsize} fp64, device-resident, in place",
+           "value": slabs * steps / dt, "unit": "4x4-slab Laplacians/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "roofline": {"bound": "hbm", "achieved": ab / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
+                        "kernel_ms_avg": kms}}
+    if with_cpu:
+        from oracle import bwk as B
+        B.build_lib()
+        cpu = {}
+        if B.ref_exe(16) is not None:
+            ts = sorted(B.run_reference(16)[2] for _ in range(5))
+            cpu = {"value": 16 * nlev * qsize / ts[len(ts) // 2], "unit": "4x4-slab Laplacians/s", "cores": 1,
+                   "kind": "reference", "sample": "reference executable (amdflang -O3 -ffp-contract=off), its shipped "
+                   "size nelemd=16, median of 5 runs (its own 'CPU time' line)"}
+        inp = B.make_inputs(64)
+        t0 = time.perf_counter(); B.biharmonic(inp); t1 = time.perf_counter() - t0
+        if not cpu:
+            cpu = {"value": 64 * nlev * qsize / t1, "unit": "4x4-slab Laplacians/s", "cores": 1, "kind": "port",
+                   "sample": "C restatement, nelemd=64"}
+        cpu["port_serial"] = 64 * nlev * qsize / t1
+        out["cpu_baseline"] = cpu
     return out
 
 
@@ -278,6 +329,15 @@ def main():
                              "unit": "GB/s", "frac": ab / (ka * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": ab, "kernel_ms_avg": ka}}
         del fs3, d3
+        torch.cuda.empty_cache()
+
+    # ---- side measurement: the second kernel, rank 0 only -------------------
+    if not args.no_bwk and rank == 0 and not f32 and ntr == 1:
+        try:
+            result["biharmonic_wk"] = bench_bwk(torch, dev, min(steps, 50), min(warmup, 50),
+                                                world == 1 and not args.no_cpu_baseline)
+        except Exception as exc:   # a side measurement must not take the headline down
+            result["biharmonic_wk"] = {"error": repr(exc)}
         torch.cuda.empty_cache()
 
     # ---- optional: scatter/gather over RCCL (outside any timed region) ------

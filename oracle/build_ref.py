@@ -119,7 +119,68 @@ def build(ncrms, nx, nz, force=False, f32=False):
     return exe
 
 
+# ---------------------------------------------------------------------------------------
+# second mini-app: atmosphere/biharmonic_wk_kernel.F90
+BWK_SRC = "/root/reference/atmosphere/biharmonic_wk_kernel.F90"
+
+
+def bwk_exe_path(nelemd):
+    return os.path.join(OUT_DIR, f"bwk_ref_ne{nelemd}")
+
+
+def build_bwk(nelemd, force=False):
+    """Build oracle/_ref/bwk_ref_ne<nelemd> from the reference program.  In-memory edits to a
+    scratch copy (deleted after the compile): :15,:17 nelemd / nete -> the requested number of
+    elements; after :559 (save_qtens) -> stream-binary dump of the inputs the program
+    generated itself (re-drawn by initialize_data, its LCG is deterministic: dvv, the
+    elements, qtens) to ./bwk_in.bin and of the CPU routine's qtens to ./bwk_out.bin.  The
+    arithmetic (:109-200) and the generator (:48-58, :77-91) are untouched."""
+    exe = bwk_exe_path(nelemd)
+    if os.path.exists(exe) and not force:
+        return exe
+    if not os.path.exists(BWK_SRC):
+        raise FileNotFoundError(f"{BWK_SRC} not present (the reference does not travel)")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(BWK_SRC) as fh:
+        lines = fh.read().split("\n")
+
+    def expect(lineno, pattern):
+        if not re.search(pattern, lines[lineno - 1]):
+            raise RuntimeError(f"reference line {lineno} is not what build_ref.py expects: {lines[lineno - 1]!r}")
+
+    expect(15, r"integer :: nelemd = 16")
+    expect(17, r"integer :: nete = 16")
+    expect(559, r"call save_qtens\(\)")
+    lines[14] = f"  integer :: nelemd = {nelemd}"
+    lines[16] = f"  integer :: nete = {nelemd}"
+    lines[558] = (lines[558] + "\n"
+                  "  open(unit=92, file='bwk_out.bin', access='stream', form='unformatted', status='replace')\n"
+                  "  write(92) qtens\n  close(92)\n"
+                  "  call initialize_data()\n"
+                  "  open(unit=91, file='bwk_in.bin', access='stream', form='unformatted', status='replace')\n"
+                  "  write(91) deriv%dvv\n"
+                  "  block\n    integer :: ie_dump\n    do ie_dump = 1, nelemd\n"
+                  "      write(91) elem(ie_dump)%Dinv, elem(ie_dump)%spheremp, elem(ie_dump)%tensorVisc\n"
+                  "    end do\n  end block\n"
+                  "  write(91) qtens\n  close(91)\n"
+                  "  qtens = qtens_save")
+    tmp = tempfile.mkdtemp(prefix="bwk_ref_")
+    try:
+        src = os.path.join(tmp, "ref_patched.F90")
+        with open(src, "w") as fh:
+            fh.write("\n".join(lines))
+        subprocess.run([FC, "-O3", "-ffp-contract=off", "-o", exe, src], check=True, cwd=tmp)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return exe
+
+
 if __name__ == "__main__":
+    if "--bwk" in sys.argv[1:]:
+        for a in sys.argv[1:]:
+            if a != "--bwk":
+                print(build_bwk(int(a), force=True))
+        sys.exit(0)
     f32 = "--f32" in sys.argv[1:]
     args = [int(a) for a in sys.argv[1:] if a != "--f32"]
     if not args or len(args) % 3:

@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from oracle import build_ref  # noqa: E402
 from oracle import oracle as O  # noqa: E402
+from oracle import bwk as B  # noqa: E402
 
 # (ncrms, nx, nz, seed, dist)
 CASES = [
@@ -76,6 +77,23 @@ def main():
             "f_min": float(f.min()), "f_max": float(f.max()),
         })
         print(name, f.shape, flux.shape)
+    # second mini-app (atmosphere/biharmonic_wk_kernel.F90): the reference program generates
+    # its own inputs (a portable LCG); fixtures = the qtens its CPU routine returns.  One
+    # element in full, the shipped size (16 elements) as a sha256.
+    manifest["bwk"] = {"reference": "atmosphere/biharmonic_wk_kernel.F90 (biharmonic_wk_scalar CPU, :186-200; "
+                                    "inputs: initialize_data :48-58)", "cases": []}
+    for nelemd, keep in ((1, True), (16, False)):
+        build_ref.build_bwk(nelemd)
+        inp, out, _ = B.run_reference(nelemd)
+        name = f"bwk_ref_ne{nelemd}"
+        if keep:
+            np.savez(os.path.join(HERE, name + ".npz"), qtens=out)
+        manifest["bwk"]["cases"].append({
+            "name": name, "nelemd": nelemd, "nlev": B.NLEV, "qsize": B.QSIZE, "stored": keep,
+            "qtens_out_sha256": hashlib.sha256(out.tobytes(order="F")).hexdigest(),
+            "inputs_sha256": hashlib.sha256(b"".join(inp[k].tobytes(order="F") for k in ("dvv", "elem", "qtens"))).hexdigest(),
+            "out_min": float(out.min()), "out_max": float(out.max())})
+        print(name, out.shape)
     with open(os.path.join(HERE, "manifest.json"), "w") as fh:
         json.dump(manifest, fh, indent=1)
 

@@ -9,9 +9,9 @@ for i in 1 2 3; do
   for v in "$@"; do
     s=$v; [ "$v" = "-" ] && s=""
     echo "== lib$s $i" >> gpurun_out/ab2.log
-    MPDATA_HIP_LIB=$PWD/codesign-kernels_amd/libmpdata_hip$s.so timeout -k 10 120 python bench.py --no-cpu-baseline --no-batched --no-fp32 >> gpurun_out/ab2.log 2>&1
+    MPDATA_HIP_LIB=$PWD/codesign-kernels_amd/libmpdata_hip$s.so timeout -k 10 120 python bench.py --no-cpu-baseline --no-batched --no-fp32 --no-bwk >> gpurun_out/ab2.log 2>&1
     echo "== lib$s T25 $i" >> gpurun_out/ab2.log
-    MPDATA_HIP_LIB=$PWD/codesign-kernels_amd/libmpdata_hip$s.so timeout -k 10 120 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-fp32 --tracers 25 >> gpurun_out/ab2.log 2>&1
+    MPDATA_HIP_LIB=$PWD/codesign-kernels_amd/libmpdata_hip$s.so timeout -k 10 120 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-fp32 --no-bwk --tracers 25 >> gpurun_out/ab2.log 2>&1
   done
 done
 python - <<'PY'

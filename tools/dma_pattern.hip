@@ -11,8 +11,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)(unsigned)bytes, 0x00020000);
 }
 // G = instances per workgroup (row segment = 8*G bytes), DW = bytes per lane of one DMA
-template <int G, int DW>
-__global__ void __launch_bounds__(512) skel(const double* f, const double* u, const double* w, double* fo,
+template <int G, int DW, int THREADS = 512>
+__global__ void __launch_bounds__(THREADS) skel(const double* f, const double* u, const double* w, double* fo,
                                             long long ncrms, int nx, int nzm) {
   // gridDim.x < number of groups: persistent workgroups, each sweeps several groups one
   // after the other (all resident workgroups then stay on about the same column)
@@ -22,7 +22,8 @@ __global__ void __launch_bounds__(512) skel(const double* f, const double* u, co
   constexpr int ARR = 32 * G;                 // doubles per array block (32 rows)
   constexpr int SLOT = 3 * ARR;
   constexpr int NI = 3 * 32 / RPI;            // instructions per column (3 arrays x 32 rows)
-  constexpr int PER_WAVE = (NI + 7) / 8;
+  constexpr int NW = THREADS / 64;
+  constexpr int PER_WAVE = (NI + NW - 1) / NW;
   __shared__ double lds[4 * SLOT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -35,20 +36,20 @@ __global__ void __launch_bounds__(512) skel(const double* f, const double* u, co
   unsigned voff[PER_WAVE]; int arr[PER_WAVE], blk[PER_WAVE];
 #pragma unroll
   for (int it = 0; it < PER_WAVE; ++it) {
-    int j = wave + 8 * it; if (j >= NI) j = NI - 1;
+    int j = wave + NW * it; if (j >= NI) j = NI - 1;
     arr[it] = j / (32 / RPI); blk[it] = j % (32 / RPI);
     const int lanes_per_row = ROWB / DW;
     int row = blk[it] * RPI + lane / lanes_per_row; if (row > nzm - 1) row = nzm - 1;
     voff[it] = (unsigned)((sl0 + ncrms * (long long)(nx + 6) * row) * 8) + (lane % lanes_per_row) * DW;
   }
   // store mapping: thread -> (row, instance)
-  constexpr int NST = G / 16;                 // row stores per thread and step
+  constexpr int NST = (32 * G + THREADS - 1) / THREADS;  // row stores per thread and step
   constexpr int VM = NST + PER_WAVE;          // vector-memory ops per wave and step
   const int t_sl = tid % G;
   int t_row[NST]; unsigned tf[NST];
 #pragma unroll
   for (int i = 0; i < NST; ++i) {
-    t_row[i] = tid / G + i * (512 / G);
+    t_row[i] = tid / G + i * (THREADS / G);
     const bool act = t_row[i] < nzm;
     tf[i] = act ? (unsigned)((sl0 + t_sl + ncrms * (long long)(nx + 6) * t_row[i]) * 8) : 0xFFFFFFF8u;
     if (!act) t_row[i] = 0;
@@ -70,10 +71,11 @@ __global__ void __launch_bounds__(512) skel(const double* f, const double* u, co
     dma(c);
   }
   for (int q = 0; q < nx + 6; ++q) {
-    static_assert(VM == 7 || VM == 3 || VM == 14 || VM == 5, "add the wait for this op count");
+    static_assert(VM == 7 || VM == 3 || VM == 14 || VM == 5 || VM == 2, "add the wait for this op count");
     if (VM == 7) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
     else if (VM == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     else if (VM == 14) asm volatile("s_waitcnt vmcnt(28) lgkmcnt(0)" ::: "memory");
+    else if (VM == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -89,18 +91,18 @@ __global__ void __launch_bounds__(512) skel(const double* f, const double* u, co
   __builtin_amdgcn_s_barrier();
   }
 }
-template <int G, int DW>
+template <int G, int DW, int THREADS = 512>
 void run(const double* f, const double* u, const double* w, double* fo, long long ncrms, int nx, int nzm, int persist = 0) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int blocks = persist ? persist : (int)(ncrms / G);
   for (int r = 0; r < 60; ++r)  // warm-up: the first ~30 ms after idle run 5-10 % slow
-    hipLaunchKernelGGL((skel<G, DW>), dim3(blocks), dim3(512), 0, 0, f, u, w, fo, ncrms, nx, nzm);
+    hipLaunchKernelGGL((skel<G, DW, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, f, u, w, fo, ncrms, nx, nzm);
   hipEventRecord(e0);
-  for (int r = 0; r < 60; ++r) hipLaunchKernelGGL((skel<G, DW>), dim3(blocks), dim3(512), 0, 0, f, u, w, fo, ncrms, nx, nzm);
+  for (int r = 0; r < 60; ++r) hipLaunchKernelGGL((skel<G, DW, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, f, u, w, fo, ncrms, nx, nzm);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 60;
   const double bytes = (double)ncrms * nzm * (nx + 6) * 8.0 * 4;  // 3 reads + 1 write
-  printf("blocks %5d G=%2d (%3d-B rows) DMA %2d B/lane: %.3f ms  %.2f TB/s (err %d)\n", blocks, G, G * 8, DW, ms, bytes / (ms * 1e-3) / 1e12, (int)hipGetLastError());
+  printf("threads %4d blocks %5d G=%2d (%3d-B rows) DMA %2d B/lane: %.3f ms  %.2f TB/s (err %d)\n", THREADS, blocks, G, G * 8, DW, ms, bytes / (ms * 1e-3) / 1e12, (int)hipGetLastError());
 }
 int main(int argc, char** argv) {
   // argv[1] = 1: stagger the arrays by 256 B each (different offsets modulo 1 KiB)
@@ -122,6 +124,10 @@ int main(int argc, char** argv) {
     run<16, 4>(f, u, w, f, ncrms, nx, nzm);
     run<32, 4>(f, u, w, f, ncrms, nx, nzm);
     run<32, 16>(f, u, w, f, ncrms, nx, nzm);
+    printf("1024-thread workgroups:\n");
+    run<32, 4, 1024>(f, u, w, fo, ncrms, nx, nzm);
+    run<32, 16, 1024>(f, u, w, fo, ncrms, nx, nzm);
+    run<32, 4, 1024>(f, u, w, f, ncrms, nx, nzm);
     printf("persistent:\n");
     run<16, 4>(f, u, w, fo, ncrms, nx, nzm, 512);
     run<16, 4>(f, u, w, fo, ncrms, nx, nzm, 1024);

@@ -10,8 +10,8 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline --no-batched --no-fp32"
-S="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batched --no-fp32"
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-batched --no-fp32 --no-bwk"
+S="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batched --no-fp32 --no-bwk"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o run -- $B > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- $S > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/write -o run -- $S > $OUT/write.log 2>&1
