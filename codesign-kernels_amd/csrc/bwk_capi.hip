@@ -51,7 +51,8 @@ int bwk_biharmonic_wk_scalar_device(int64_t nelemd, int nlev, int qsize, double*
   int rc = validate(nelemd, nlev, qsize);
   if (rc) return rc;
   if (!qtens || !dvv || !elem) return set_err(BWK_EINVAL, "null array pointer");
-  if (((uintptr_t)qtens & 31) != 0) return set_err(BWK_EINVAL, "qtens must be 32-byte aligned");
+  if (((uintptr_t)qtens & 31) != 0 || ((uintptr_t)elem & 31) != 0)
+    return set_err(BWK_EINVAL, "qtens and elem must be 32-byte aligned");
   if (variant() == BWK_VARIANT_FAST) bwk_fast::launch(qtens, dvv, elem, nelemd, nlev, qsize, stream);
   else bwk_exact::launch(qtens, dvv, elem, nelemd, nlev, qsize, stream);
   const hipError_t e = hipGetLastError();

@@ -17,6 +17,7 @@
 //     EXACT build (-ffp-contract=off) is bit-identical to the reference CPU routine.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace BWK_NS {
 
@@ -64,27 +65,36 @@ __global__ void __launch_bounds__(BWK_THREADS, 2) bwk_kernel(const BwkArgs g) {
   }
   // the element at the lane's points (a, n): Dinv(a,n,c,d) = el[a + 4*(n + 4*(c + 2*d))],
   // spheremp(a,n) = el[64 + a + 4n], tensorVisc(a,n,c,d) = el[80 + a + 4*(n + 4*(c + 2*d))]
+  // (the 4 points of the lane's column are 4 consecutive doubles of each block: 32-byte loads)
   double Di[4][2][2], Tv[4][2][2], Sp[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    Sp[a] = el[64 + a + 4 * n];
+  {
+    const d4 sp = *reinterpret_cast<const d4*>(el + 64 + 4 * n);
+    Sp[0] = sp.x; Sp[1] = sp.y; Sp[2] = sp.z; Sp[3] = sp.w;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        Di[a][c][d] = el[a + 4 * (n + 4 * (c + 2 * d))];
-        Tv[a][c][d] = el[80 + a + 4 * (n + 4 * (c + 2 * d))];
+        const d4 di = *reinterpret_cast<const d4*>(el + 4 * (n + 4 * (c + 2 * d)));
+        const d4 tv = *reinterpret_cast<const d4*>(el + 80 + 4 * (n + 4 * (c + 2 * d)));
+        Di[0][c][d] = di.x; Di[1][c][d] = di.y; Di[2][c][d] = di.z; Di[3][c][d] = di.w;
+        Tv[0][c][d] = tv.x; Tv[1][c][d] = tv.y; Tv[2][c][d] = tv.z; Tv[3][c][d] = tv.w;
       }
   }
 
   const long long slab0 = (long long)blockIdx.x * g.passes * BWK_SLABS_PER_PASS + (tid >> 2);
   double* const base = g.qtens + (ie * g.nslab) * 16 + n * 4;
+  // software pipeline: the loads of pass p+1 are in flight while pass p is computed (a wave
+  // moves only 2 KB per pass; without this the chip has too few bytes in flight to fill HBM)
+  d4 nxt = d4{0.0, 0.0, 0.0, 0.0};
+  if (slab0 < g.nslab) nxt = *reinterpret_cast<const d4*>(base + slab0 * 16);
   for (int p = 0; p < g.passes; ++p) {
     const long long slab = slab0 + (long long)p * BWK_SLABS_PER_PASS;
     // a quad is whole or not at all inside the element: the DPP broadcasts below stay valid
     if (slab >= g.nslab) break;
     double* const ptr = base + slab * 16;
-    const d4 sv = *reinterpret_cast<const d4*>(ptr);
+    const d4 sv = nxt;
+    if (p + 1 < g.passes && slab + BWK_SLABS_PER_PASS < g.nslab)
+      nxt = *reinterpret_cast<const d4*>(ptr + BWK_SLABS_PER_PASS * 16);
     const double sc[4] = {sv.x, sv.y, sv.z, sv.w};
 
     // ---- gradient_sphere (:109-134) -----------------------------------------------------
@@ -142,9 +152,14 @@ void launch(double* qtens, const double* dvv, const double* elem, long long nele
   BwkArgs g;
   g.qtens = qtens; g.dvv = dvv; g.elem = elem; g.nelemd = nelemd;
   g.nslab = nlev * qsize;
-  // ~8 passes per workgroup amortise the per-workgroup constant loads
+  // passes per workgroup: more amortise the per-workgroup constant loads, fewer give the
+  // dispatcher more, shorter workgroups; measured at nelemd=5400: 8 -> 5.05, 16 -> 5.3,
+  // 24 -> 4.8 TB/s (BWK_PASSES overrides the cap of 16, for experiments)
   const int total_passes = (g.nslab + BWK_SLABS_PER_PASS - 1) / BWK_SLABS_PER_PASS;
-  g.passes = total_passes < 8 ? total_passes : 8;
+  static const int want = [] { const char* v = getenv("BWK_PASSES"); return v ? atoi(v) : 16; }();
+  const int cap = want < 1 ? 1 : want;
+  const int nwg = (total_passes + cap - 1) / cap;          // workgroups per element ...
+  g.passes = (total_passes + nwg - 1) / nwg;               // ... of equal length (45 passes -> 3 x 15)
   const unsigned gx = (unsigned)((total_passes + g.passes - 1) / g.passes);
   hipLaunchKernelGGL(bwk_kernel, dim3(gx, (unsigned)nelemd, 1), dim3(BWK_THREADS), 0, (hipStream_t)stream, g);
 }

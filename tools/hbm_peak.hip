@@ -12,6 +12,11 @@ __global__ void __launch_bounds__(256) k_read(const d2* a, const d2* b, const d2
 __global__ void __launch_bounds__(256) k_copy(const d2* a, d2* o, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = a[i];
 }
+// in place: o[i] = 1.0000001 * o[i] (what biharmonic_wk_scalar does to qtens); 32 B per lane
+typedef double d4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_inplace(d4* o, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) o[i] = o[i] * 1.0000001;
+}
 __global__ void __launch_bounds__(256) k_mix(const d2* a, const d2* b, const d2* c, d2* o, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = a[i] + b[i] + c[i];
 }
@@ -27,20 +32,21 @@ int main(int argc, char** argv) {
   (void)hipMemset(a, 0, bytes); (void)hipMemset(b, 0, bytes); (void)hipMemset(c, 0, bytes); (void)hipMemset(o, 0, bytes);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int grid : {2048, 8192, 65536}) {
-    for (int which = 0; which < 3; ++which) {
+    for (int which = 0; which < 4; ++which) {
       float best = 1e9f, sum = 0; int cnt = 0;
       for (int r = 0; r < 60; ++r) {
         (void)hipEventRecord(e0);
         if (which == 0) hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, a, b, c, o, n);
         if (which == 1) hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, a, o, n);
         if (which == 2) hipLaunchKernelGGL(k_mix, dim3(grid), dim3(256), 0, 0, a, b, c, o, n);
+        if (which == 3) hipLaunchKernelGGL(k_inplace, dim3(grid), dim3(256), 0, 0, (d4*)o, n / 2);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (r >= 20) { sum += ms; ++cnt; }
         if (r > 0 && ms < best) best = ms;
       }
-      const double moved = (double)bytes * (which == 0 ? 3 : which == 1 ? 2 : 4);
-      printf("grid %6d %-10s best %.3f ms %.2f TB/s   mean(steady) %.3f ms %.2f TB/s\n", grid, which == 0 ? "read 3R" : which == 1 ? "copy 1R:1W" : "mix 3R:1W", best, moved / (best * 1e-3) / 1e12, sum / cnt, moved / (sum / cnt * 1e-3) / 1e12);
+      const double moved = (double)bytes * (which == 0 ? 3 : which == 1 ? 2 : which == 2 ? 4 : 2);
+      printf("grid %6d %-10s best %.3f ms %.2f TB/s   mean(steady) %.3f ms %.2f TB/s\n", grid, which == 0 ? "read 3R" : which == 1 ? "copy 1R:1W" : which == 2 ? "mix 3R:1W" : "in place 1R:1W", best, moved / (best * 1e-3) / 1e12, sum / cnt, moved / (sum / cnt * 1e-3) / 1e12);
     }
   }
   return 0;

@@ -72,3 +72,24 @@ with open(os.path.join(dst, "hbm_traffic.json"), "w") as fh:
                                 "source": f"profiles/{tag}_pmc_summary.json (same loads/stores in both variants)"}},
               fh, indent=1)
 print(json.dumps(summary, indent=1))
+
+# ---- second kernel: biharmonic_wk_scalar (tools/bwk_bench.py: nelemd=5400, both variants) ----
+if glob.glob(os.path.join(src, "bwk_kt", "**", "*_kernel_stats.csv"), recursive=True):
+    KERNEL = "bwk_kernel"
+    shutil.copy(one("bwk_kt/**/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_bwk_kernel_stats.csv"))
+    rows = {}
+    with open(os.path.join(dst, f"{tag}_bwk_kernel_stats.csv")) as fh:
+        for row in csv.DictReader(fh):
+            if KERNEL in row["Name"]:
+                rows[row["Name"]] = {"avg_ns": float(row["AverageNs"]), "calls": int(row["Calls"])}
+    bf, bw = counters("bwk_fetch"), counters("bwk_write")
+    brd = bf["FETCH_SIZE"][0] / bf["FETCH_SIZE"][1] * 1024 * 2
+    bwr = bw["WRITE_SIZE"][0] / bw["WRITE_SIZE"][1] * 1024
+    balg = 2 * 8 * 16 * 72 * 40 * 5400 + 8 * (144 * 5400 + 16)
+    bsum = {"kernel": "bwk_kernel (biharmonic_wk_scalar), nelemd=5400 nlev=72 qsize=40", "kernel_trace": rows,
+            "hbm_read_bytes_per_launch": brd, "hbm_write_bytes_per_launch": bwr,
+            "algorithmic_bytes_per_launch": balg, "ratio_traffic_over_algorithmic": (brd + bwr) / balg,
+            "commands": "tools/profile_round.sh (python3 tools/bwk_bench.py --child -)"}
+    with open(os.path.join(dst, f"{tag}_bwk_summary.json"), "w") as fh:
+        json.dump(bsum, fh, indent=1)
+    print(json.dumps(bsum, indent=1))

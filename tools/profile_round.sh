@@ -16,5 +16,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o run -- $B > $
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- $S > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/write -o run -- $S > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/sq -o run -- $S > $OUT/sq.log 2>&1
+# second kernel (biharmonic_wk_scalar, nelemd=5400): kernel trace + HBM traffic
+W="python3 $ROOT/tools/bwk_bench.py --child -"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bwk_kt -o run -- $W > $OUT/bwk_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bwk_fetch -o run -- $W > $OUT/bwk_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bwk_write -o run -- $W > $OUT/bwk_write.log 2>&1
 cd $ROOT
 python3 tools/pmc_summary.py $TAG
