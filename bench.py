@@ -158,6 +158,62 @@ def bench_bwk(torch, dev, steps, warmup, with_cpu):
     return out
 
 
+def bench_nlk(torch, dev, steps, warmup, with_cpu):
+    """Side measurement of the third kernel: the MPAS-Ocean high-order flux loop
+    nest at the reference's namelist size (nested_loops/nested.nml: 25600 edges, 2800 cells,
+    100 levels, 10 cells per edge), FAST variant, device-resident."""
+    import numpy as np
+    import codesign_kernels_amd.nlk as K
+    nE, nC, nV, nA = 25600, 2800, 100, 10
+    K.set_variant(K.VARIANT_FAST)
+    g = torch.Generator(device=dev).manual_seed(3)
+    rnd = lambda *shape: torch.rand(shape, dtype=torch.float64, device=dev, generator=g)
+    d = {"nAdvCellsForEdge": torch.full((nE,), nA, dtype=torch.int32, device=dev),
+         "advCellsForEdge": torch.randint(1, nC + 1, (nE, nA), dtype=torch.int32, device=dev, generator=g),
+         "minLevelCell": torch.ones((nC,), dtype=torch.int32, device=dev),
+         "maxLevelCell": torch.clamp((rnd(nC) * nV * 2).round().to(torch.int32), 3, nV),
+         "tracerCur": 15.0 * rnd(nC, nV), "normalThicknessFlux": 15.0 * (0.5 - rnd(nE, nV)),
+         "advMaskHighOrder": torch.ones((nE, nV), dtype=torch.float64, device=dev),
+         "advCoefs": 20.0 * rnd(nE, nA), "advCoefs3rd": 21.0 * rnd(nE, nA)}
+    out = torch.zeros((nE, nV), dtype=torch.float64, device=dev)
+    coef = float(np.float32(2.14))
+    for _ in range(warmup):
+        K.high_order_flux(d, nV, coef, out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        K.high_order_flux(d, nV, coef, out)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms = e0.elapsed_time(e1) / steps
+    ab = K.algorithmic_bytes(nE, nC, nV, nV, nA)
+    res = {"workload": f"nested_loops/nested.F90 high-order flux loop nest: nEdges={nE} nCells={nC} "
+                       f"nVertLevels={nV} nAdv={nA} fp64, device-resident",
+           "value": nE * nV * steps / dt, "unit": "edge-level fluxes/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "roofline": {"bound": "hbm", "achieved": ab / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
+                        "kernel_ms_avg": kms,
+                        "note": "62 MB per call: the working set fits the 256-MB Infinity Cache and the call is "
+                                "short; launch-latency territory, not an HBM-bound measurement"}}
+    if with_cpu:
+        from oracle import nlk as N
+        N.build_lib()
+        inp = N.make_inputs(nE, nC, nV, nA, seed=1, ragged=False)
+        best = min(_timeit(lambda: N.high_order_flux(inp)) for _ in range(3))
+        res["cpu_baseline"] = {"value": nE * nV / best, "unit": "edge-level fluxes/s", "cores": 1, "kind": "port",
+                               "sample": "C restatement of nested.F90:123-157, the namelist size, best of 3"}
+    return res
+
+
+def _timeit(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
+
+
 def make_problem(M, torch, dev, ncrms_loc, ncrms_glob, sl0, nx, nz, ntr, nbuf, dist, dtype=None):
     dtype = torch.float64 if dtype is None else dtype
     sh = M.shapes(ncrms_loc, nx, nz, ntr)
@@ -338,6 +394,11 @@ def main():
                                                 world == 1 and not args.no_cpu_baseline)
         except Exception as exc:   # a side measurement must not take the headline down
             result["biharmonic_wk"] = {"error": repr(exc)}
+        try:
+            result["high_order_flux"] = bench_nlk(torch, dev, min(steps, 100), min(warmup, 20),
+                                                  world == 1 and not args.no_cpu_baseline)
+        except Exception as exc:
+            result["high_order_flux"] = {"error": repr(exc)}
         torch.cuda.empty_cache()
 
     # ---- optional: scatter/gather over RCCL (outside any timed region) ------

@@ -1,0 +1,55 @@
+// nlk_kernel_body.h -- HIP kernel of the MPAS-Ocean high-order flux loop nest for gfx950
+// (reference nested_loops/nested.F90:123-157 / :495-559; included once per arithmetic variant
+// with NLK_NS defined).
+//
+// A WAVE owns one edge, its lanes the vertical levels (level index is the contiguous one, so
+// every row access is a coalesced 512-byte segment; 100 levels = two trips).  The loop over
+// the contributing cells stays sequential per level -- the reference's summation order --
+// and everything that is per (edge, i) is wave-uniform: cell index, coefficients and the
+// cell's level range come through scalar loads, the level-range test is a lane mask.  The
+// gathered tracer columns (2.2 MB at the reference's size) live in L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nlk_args.h"
+
+namespace NLK_NS {
+
+constexpr int NLK_WAVES = 4;  // edges per workgroup
+
+__global__ void __launch_bounds__(64 * NLK_WAVES) nlk_kernel(const NlkArgs g) {
+  const int lane = threadIdx.x & 63;
+  const int iEdge = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * NLK_WAVES + (threadIdx.x >> 6)));
+  if (iEdge >= g.nEdges) return;
+  const long long erow = (long long)g.nvldim * iEdge;
+  int nadv = g.nAdvCellsForEdge[iEdge];
+  nadv = nadv < g.nAdv ? nadv : g.nAdv;
+  const int* cells = g.advCellsForEdge + (long long)g.nAdv * iEdge;
+  const double* c1p = g.advCoefs + (long long)g.nAdv * iEdge;
+  const double* c3p = g.advCoefs3rd + (long long)g.nAdv * iEdge;
+  for (int k0 = 0; k0 < g.nVertLevels; k0 += 64) {
+    const int k = k0 + lane + 1;  // 1-based level
+    const bool lvl = k <= g.nVertLevels;
+    const double ntf = lvl ? g.normalThicknessFlux[erow + k - 1] : 0.0;
+    const double wgt = ntf * (lvl ? g.advMaskHighOrder[erow + k - 1] : 0.0);   // :126-127
+    const double sgn = __builtin_copysign(1.0, ntf);                           // :128-129
+    double acc = 0.0;
+    for (int i = 0; i < nadv; ++i) {                                           // :136-148
+      const int iCell = cells[i];
+      if (iCell < 1 || iCell > g.nCells) continue;   // (the reference would read out of bounds)
+      const int kmin = g.minLevelCell[iCell - 1], kmax = g.maxLevelCell[iCell - 1];
+      const double coef1 = c1p[i];
+      const double coef3 = c3p[i] * g.coef3rdOrder;
+      if (lvl && k >= kmin && k <= kmax)
+        acc = acc + g.tracerCur[(long long)g.nvldim * (iCell - 1) + k - 1] * wgt * (coef1 + coef3 * sgn);
+    }
+    if (lvl) g.highOrderFlx[erow + k - 1] = acc;
+  }
+}
+
+void launch(const NlkArgs& g, void* stream) {
+  const unsigned gx = (unsigned)((g.nEdges + NLK_WAVES - 1) / NLK_WAVES);
+  hipLaunchKernelGGL(nlk_kernel, dim3(gx), dim3(64 * NLK_WAVES), 0, (hipStream_t)stream, g);
+}
+
+}  // namespace NLK_NS

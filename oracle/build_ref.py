@@ -175,7 +175,70 @@ def build_bwk(nelemd, force=False):
     return exe
 
 
+# ---------------------------------------------------------------------------------------
+# third mini-app: nested_loops/nested.F90 ("after that")
+NLK_DIR = "/root/reference/nested_loops"
+
+
+def nlk_exe_path():
+    return os.path.join(OUT_DIR, "nlk_ref")
+
+
+def build_nlk(force=False):
+    """Build oracle/_ref/nlk_ref from nested_loops/{timerMod.f90,nested_vars.F90,nested.F90}
+    with -DNO_MPI (plain CPU build: no OpenACC/OpenMP-offload/YAKL/CKE).  In-memory edits to a
+    scratch copy of nested.F90 (deleted after the compile): the six `call random_number(randNum)`
+    (:65,:75,:90,:92,:94,:103) -> stream reads of randNum from ./nlk_rand.bin (the compiler's
+    RNG is not reproducible across compilers); after the program's own CPU reference loop
+    (:157) -> stream dump of the sizes, every input array and refFlx to ./nlk_out.bin, then
+    `stop`.  Sizes come from ./nested.nml as in the reference.  The loop (:123-157) is untouched."""
+    exe = nlk_exe_path()
+    if os.path.exists(exe) and not force:
+        return exe
+    src_main = os.path.join(NLK_DIR, "nested.F90")
+    if not os.path.exists(src_main):
+        raise FileNotFoundError(f"{src_main} not present (the reference does not travel)")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(src_main) as fh:
+        lines = fh.read().split("\n")
+
+    def expect(lineno, pattern):
+        if not re.search(pattern, lines[lineno - 1]):
+            raise RuntimeError(f"reference line {lineno} is not what build_ref.py expects: {lines[lineno - 1]!r}")
+
+    for ln in (65, 75, 90, 92, 94, 103):
+        expect(ln, r"call random_number\(randNum\)")
+        lines[ln - 1] = lines[ln - 1].replace("call random_number(randNum)", "read(91) randNum")
+    expect(48, r"call alloc_vars")
+    lines[47] = (lines[47] + "\n   open(unit=91, file='nlk_rand.bin', access='stream', form='unformatted', status='old')")
+    expect(157, r"end do ! edge loop")
+    lines[156] = (lines[156] + "\n"
+                  "   close(91)\n"
+                  "   open(unit=92, file='nlk_out.bin', access='stream', form='unformatted', status='replace')\n"
+                  "   write(92) nEdges, nCells, nVertLevels, nvldim, nAdv\n"
+                  "   write(92) nAdvCellsForEdge, advCellsForEdge, minLevelCell, maxLevelCell\n"
+                  "   write(92) tracerCur, normalThicknessFlux, advMaskHighOrder, advCoefs, advCoefs3rd\n"
+                  "   write(92) coef3rdOrder\n"
+                  "   write(92) refFlx\n"
+                  "   close(92)\n"
+                  "   stop")
+    tmp = tempfile.mkdtemp(prefix="nlk_ref_")
+    try:
+        src = os.path.join(tmp, "nested_patched.F90")
+        with open(src, "w") as fh:
+            fh.write("\n".join(lines))
+        subprocess.run([FC, "-O3", "-ffp-contract=off", "-DNO_MPI", "-o", exe,
+                        os.path.join(NLK_DIR, "timerMod.f90"), os.path.join(NLK_DIR, "nested_vars.F90"), src],
+                       check=True, cwd=tmp)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return exe
+
+
 if __name__ == "__main__":
+    if "--nlk" in sys.argv[1:]:
+        print(build_nlk(force=True))
+        sys.exit(0)
     if "--bwk" in sys.argv[1:]:
         for a in sys.argv[1:]:
             if a != "--bwk":

@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 from oracle import build_ref  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from oracle import bwk as B  # noqa: E402
+from oracle import nlk as N  # noqa: E402
 
 # (ncrms, nx, nz, seed, dist)
 CASES = [
@@ -94,6 +95,20 @@ def main():
             "inputs_sha256": hashlib.sha256(b"".join(inp[k].tobytes(order="F") for k in ("dvv", "elem", "qtens"))).hexdigest(),
             "out_min": float(out.min()), "out_max": float(out.max())})
         print(name, out.shape)
+    # third mini-app (nested_loops/nested.F90): the program's inputs depend on the compiler's
+    # random_number, so the reference is fed a seeded stream (oracle/build_ref.py --nlk) and the
+    # fixture keeps the inputs the PROGRAM built from it together with its refFlx.
+    build_ref.build_nlk()
+    manifest["nlk"] = {"reference": "nested_loops/nested.F90 (CPU reference loop :123-157 -> refFlx)", "cases": []}
+    for name, shape, seed, keep in (("nlk_ref_small", (64, 20, 12, 4), 5, True),
+                                    ("nlk_ref_nml", (25600, 2800, 100, 10), 5, False)):
+        inp, ref = N.run_reference(*shape, seed=seed)
+        if keep:
+            np.savez(os.path.join(HERE, name + ".npz"), refFlx=ref, **{k: v for k, v in inp.items()})
+        manifest["nlk"]["cases"].append({
+            "name": name, "nEdges": shape[0], "nCells": shape[1], "nVertLevels": shape[2], "nAdv": shape[3],
+            "seed": seed, "stored": keep, "refFlx_sha256": hashlib.sha256(ref.tobytes(order="F")).hexdigest()})
+        print(name, ref.shape)
     with open(os.path.join(HERE, "manifest.json"), "w") as fh:
         json.dump(manifest, fh, indent=1)
 
