@@ -34,14 +34,29 @@ __global__ void __launch_bounds__(64 * NLK_WAVES) nlk_kernel(const NlkArgs g) {
     const double wgt = ntf * (lvl ? g.advMaskHighOrder[erow + k - 1] : 0.0);   // :126-127
     const double sgn = __builtin_copysign(1.0, ntf);                           // :128-129
     double acc = 0.0;
-    for (int i = 0; i < nadv; ++i) {                                           // :136-148
-      const int iCell = cells[i];
-      if (iCell < 1 || iCell > g.nCells) continue;   // (the reference would read out of bounds)
-      const int kmin = g.minLevelCell[iCell - 1], kmax = g.maxLevelCell[iCell - 1];
-      const double coef1 = c1p[i];
-      const double coef3 = c3p[i] * g.coef3rdOrder;
-      if (lvl && k >= kmin && k <= kmax)
-        acc = acc + g.tracerCur[(long long)g.nvldim * (iCell - 1) + k - 1] * wgt * (coef1 + coef3 * sgn);
+    // the gathers of CH cells are issued together (they do not depend on the running sum);
+    // the additions then follow in the reference's order i ascending
+    constexpr int CH = 5;
+    for (int i0 = 0; i0 < nadv; i0 += CH) {                                    // :136-148
+      double t[CH], f[CH];
+      bool on[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int i = i0 + j;
+        const bool have = i < nadv;
+        const int iCell = have ? cells[i] : 0;
+        const bool cell_ok = iCell >= 1 && iCell <= g.nCells;   // (the reference would read out of bounds)
+        const int ic = cell_ok ? iCell - 1 : 0;
+        const int kmin = g.minLevelCell[ic], kmax = g.maxLevelCell[ic];
+        on[j] = cell_ok && lvl && k >= kmin && k <= kmax;
+        t[j] = on[j] ? g.tracerCur[(long long)g.nvldim * ic + k - 1] : 0.0;
+        const double coef1 = have ? c1p[i] : 0.0;
+        const double coef3 = (have ? c3p[i] : 0.0) * g.coef3rdOrder;
+        f[j] = coef1 + coef3 * sgn;
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if (on[j]) acc = acc + t[j] * wgt * f[j];
     }
     if (lvl) g.highOrderFlx[erow + k - 1] = acc;
   }
