@@ -291,8 +291,24 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   // grid = (tracers, instance groups): tracer is the FASTEST block index, so the
   // workgroups that share the same rows of u,w,rho,rhow,adz are dispatched together and
   // all but the first read them from the L2 / Infinity Cache instead of HBM
-  const int tr = blockIdx.x;
-  const unsigned grp = blockIdx.y;
+  int tr = blockIdx.x;
+  unsigned grp = blockIdx.y;
+#ifndef MPD2_NO_XCD_TRACERS
+  // Tracer batches: workgroups are dealt to the 8 XCDs round-robin in dispatch order, so with
+  // the plain mapping the tracers of one instance group land on 8 different L2s.  Re-deal
+  // them: all tracers of group g go to XCD g % 8, back to back, and 24 of 25 reads of that
+  // group's u, w rows hit in that XCD's L2.
+  if (gridDim.x > 1) {
+    const unsigned ntr = gridDim.x, nxcd = 8;
+    const unsigned L = blockIdx.x + ntr * blockIdx.y;   // dispatch order (x fastest)
+    const unsigned full = (gridDim.y / nxcd) * nxcd;    // groups the re-deal covers
+    if (L < ntr * full) {
+      const unsigned xcd = L % nxcd, j = L / nxcd;
+      tr = (int)(j % ntr);
+      grp = (j / ntr) * nxcd + xcd;
+    }
+  }
+#endif
   const long long sl_base = (long long)grp * G;
 
   R* const f = a.f + (long long)tr * a.f_tstride;
