@@ -27,19 +27,27 @@ __global__ void __launch_bounds__(64 * NLK_WAVES) nlk_kernel(const NlkArgs g) {
   const int* cells = g.advCellsForEdge + (long long)g.nAdv * iEdge;
   const double* c1p = g.advCoefs + (long long)g.nAdv * iEdge;
   const double* c3p = g.advCoefs3rd + (long long)g.nAdv * iEdge;
-  for (int k0 = 0; k0 < g.nVertLevels; k0 += 64) {
-    const int k = k0 + lane + 1;  // 1-based level
-    const bool lvl = k <= g.nVertLevels;
-    const double ntf = lvl ? g.normalThicknessFlux[erow + k - 1] : 0.0;
-    const double wgt = ntf * (lvl ? g.advMaskHighOrder[erow + k - 1] : 0.0);   // :126-127
-    const double sgn = __builtin_copysign(1.0, ntf);                           // :128-129
-    double acc = 0.0;
+  // two 64-level trips are in flight together (100 levels = lanes 0..63 of trip 0 + lanes
+  // 0..35 of trip 1): twice the independent gathers per wave
+  for (int k0 = 0; k0 < g.nVertLevels; k0 += 128) {
+    int k[2];
+    bool lvl[2];
+    double wgt[2], sgn[2], acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      k[t] = k0 + 64 * t + lane + 1;  // 1-based level
+      lvl[t] = k[t] <= g.nVertLevels;
+      const double ntf = lvl[t] ? g.normalThicknessFlux[erow + k[t] - 1] : 0.0;
+      wgt[t] = ntf * (lvl[t] ? g.advMaskHighOrder[erow + k[t] - 1] : 0.0);   // :126-127
+      sgn[t] = __builtin_copysign(1.0, ntf);                                  // :128-129
+      acc[t] = 0.0;
+    }
     // the gathers of CH cells are issued together (they do not depend on the running sum);
     // the additions then follow in the reference's order i ascending
     constexpr int CH = 5;
-    for (int i0 = 0; i0 < nadv; i0 += CH) {                                    // :136-148
-      double t[CH], f[CH];
-      bool on[CH];
+    for (int i0 = 0; i0 < nadv; i0 += CH) {                                   // :136-148
+      double tv[CH][2], c1[CH], c3[CH];
+      bool on[CH][2];
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         const int i = i0 + j;
@@ -48,17 +56,23 @@ __global__ void __launch_bounds__(64 * NLK_WAVES) nlk_kernel(const NlkArgs g) {
         const bool cell_ok = iCell >= 1 && iCell <= g.nCells;   // (the reference would read out of bounds)
         const int ic = cell_ok ? iCell - 1 : 0;
         const int kmin = g.minLevelCell[ic], kmax = g.maxLevelCell[ic];
-        on[j] = cell_ok && lvl && k >= kmin && k <= kmax;
-        t[j] = on[j] ? g.tracerCur[(long long)g.nvldim * ic + k - 1] : 0.0;
-        const double coef1 = have ? c1p[i] : 0.0;
-        const double coef3 = (have ? c3p[i] : 0.0) * g.coef3rdOrder;
-        f[j] = coef1 + coef3 * sgn;
+        c1[j] = have ? c1p[i] : 0.0;
+        c3[j] = (have ? c3p[i] : 0.0) * g.coef3rdOrder;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          on[j][t] = cell_ok && lvl[t] && k[t] >= kmin && k[t] <= kmax;
+          tv[j][t] = on[j][t] ? g.tracerCur[(long long)g.nvldim * ic + k[t] - 1] : 0.0;
+        }
       }
 #pragma unroll
       for (int j = 0; j < CH; ++j)
-        if (on[j]) acc = acc + t[j] * wgt * f[j];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          if (on[j][t]) acc[t] = acc[t] + tv[j][t] * wgt[t] * (c1[j] + c3[j] * sgn[t]);
     }
-    if (lvl) g.highOrderFlx[erow + k - 1] = acc;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (lvl[t]) g.highOrderFlx[erow + k[t] - 1] = acc[t];
   }
 }
 
