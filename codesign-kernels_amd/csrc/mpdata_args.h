@@ -17,6 +17,7 @@ struct MpdataArgsT {
   R* flux;
   long long ncrms;         // CRM instances = leading dimension of every array
   int nx, nz;
+  int ntracers;            // x-marching kernels: the 1-D grid is ntracers * groups, tracer fastest
   long long f_tstride;     // elements between consecutive tracers of f
   long long flux_tstride;  // ... of flux
   unsigned long long* dbg;  // diagnostic builds only (-DMPD2_STAMPS): in-kernel clock stamps; else null

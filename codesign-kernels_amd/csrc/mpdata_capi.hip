@@ -79,8 +79,12 @@ bool get_tile(int var, int id, MpdataTileInfo* t) {
 // fp32 (elem_bytes = 4): the two-instances-per-lane kernels (tile ids >= 40) when ncrms is
 // even, else the one-instance-per-lane ones (nz <= 32).
 int choose_tile(int var, int64_t ncrms, int nx, int nz, MpdataTileInfo* out, int elem_bytes = 8) {
-  // the x-marching kernels address rows with 32-bit byte offsets inside one array
-  const bool small32 = (double)ncrms * (nx + 6) * nz * (double)elem_bytes < 4294967296.0;
+  // the x-marching kernels use 32-bit byte offsets relative to the first row a wave touches
+  // (at most 4 rows = levels of one column) plus a 32-bit column offset: arrays may exceed
+  // 4 GiB as long as four levels of one array stay below it
+  const bool small32 = (double)ncrms * (nx + 6) * 4.0 * (double)elem_bytes < 4294967000.0;
+  // the k-marching kernels (fp64 only) use 32-bit byte offsets inside one k-plane
+  const bool plane31 = (double)ncrms * (nx + 8) * 8.0 < 2147483648.0;
   int forced = tile_override();
   MpdataTileInfo t;
   if (forced >= 0 && get_tile(var, forced, &t) && t.elem_bytes != elem_bytes) forced = -1;  // other precision
@@ -88,7 +92,7 @@ int choose_tile(int var, int64_t ncrms, int nx, int nz, MpdataTileInfo* out, int
     if (!get_tile(var, forced, &t)) return set_err(MPDATA_EINVAL, "unknown tile id %d", forced);
     if (t.id >= 40 && (ncrms & 1))
       return set_err(MPDATA_EUNSUPPORTED, "tile %s needs an even ncrms", t.name);
-    if (t.ncol < nx + 4 || t.nz_max < nz || (t.nz_max < (1 << 30) && !small32))
+    if (t.ncol < nx + 4 || t.nz_max < nz || (t.nz_max < (1 << 30) ? !small32 : !plane31))
       return set_err(MPDATA_EUNSUPPORTED, "tile %s covers %d columns / nz<=%d; nx=%d nz=%d", t.name,
                      t.ncol, t.nz_max, nx, nz);
     *out = t;
@@ -101,7 +105,7 @@ int choose_tile(int var, int64_t ncrms, int nx, int nz, MpdataTileInfo* out, int
     if (t.elem_bytes != elem_bytes) continue;
     if (t.id >= 40 && (ncrms & 1)) continue;
     if (t.ncol < nx + 4 || t.nz_max < nz) continue;
-    if (t.nz_max < (1 << 30) && !small32) continue;
+    if (t.nz_max < (1 << 30) ? !small32 : !plane31) continue;
     // x-marching tiles (finite nz_max) first, by lanes per instance; then k-marching by columns
     // (among x-marching tiles of equal lanes-per-instance the smaller workgroup is the default)
     const int cost = t.nz_max < (1 << 30) ? t.nz_max * 100 + t.slw - (t.id >= 40 ? 50 : 0) : 100000 + t.ncol;
@@ -109,7 +113,8 @@ int choose_tile(int var, int64_t ncrms, int nx, int nz, MpdataTileInfo* out, int
   }
   if (best < 0)
     return set_err(MPDATA_EUNSUPPORTED,
-                   elem_bytes == 8 ? "no kernel tiling covers nx=%d nz=%d (need nz<=64 or nx<=140)"
+                   elem_bytes == 8 ? "no kernel tiling covers nx=%d nz=%d at this ncrms (need nz<=64 with 4 levels of one "
+                                     "array < 4 GiB, or nx<=140 with one k-plane < 2 GiB)"
                                    : "no fp32 kernel tiling covers nx=%d nz=%d (need nz<=64, and nz<=32 for odd ncrms)",
                    nx, nz);
   get_tile(var, best, out);
@@ -120,11 +125,10 @@ int validate(int64_t ncrms, int nx, int nz, int ntracers) {
   if (ncrms < 1 || nx < 1 || nz < 3 || ntracers < 1)
     return set_err(MPDATA_EINVAL, "bad sizes ncrms=%lld nx=%d nz=%d ntracers=%d (need >=1,>=1,>=3,>=1)",
                    (long long)ncrms, nx, nz, ntracers);
-  // 32-bit byte offsets inside one k-plane (kernel uses buffer addressing)
-  if ((double)ncrms * (nx + 8) * 8.0 >= 2147483648.0)
-    return set_err(MPDATA_EUNSUPPORTED, "ncrms*(nx+8)*8 must be < 2^31 bytes per k-plane");
   if (ntracers > 65535) return set_err(MPDATA_EUNSUPPORTED, "ntracers > 65535");
-  if ((ncrms + 15) / 16 > 65535) return set_err(MPDATA_EUNSUPPORTED, "ncrms > 16*65535 per call");
+  // one workgroup per (tracer, group of >= 16 instances) in a 1-D grid
+  if ((double)ntracers * (double)((ncrms + 15) / 16) > 2147483647.0)
+    return set_err(MPDATA_EUNSUPPORTED, "ntracers * ncrms/16 must be < 2^31 workgroups per call");
   return 0;
 }
 
@@ -220,7 +224,7 @@ int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u,
   if (rc) return rc;
   MpdataArgsT<R> a;
   a.f = f; a.u = u; a.w = w; a.rho = rho; a.rhow = rhow; a.adz = adz; a.flux = flux;
-  a.ncrms = ncrms; a.nx = nx; a.nz = nz;
+  a.ncrms = ncrms; a.nx = nx; a.nz = nz; a.ntracers = ntracers;
   a.f_tstride = (long long)ncrms * (nx + 6) * (nz - 1);
   a.flux_tstride = (long long)ncrms * nz;
   a.dbg = g_dbg;

@@ -128,8 +128,10 @@ __device__ __forceinline__ f32x2 recip_nr(f32x2 d) {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // Buffer addressing for the row transfers: wave-uniform descriptor + per-lane
 // 32-bit byte offset (VGPR) + wave-uniform byte offset of the column (SGPR).
+// The range (num_records) is clipped BELOW the out-of-range marker 0xFFFFFFF8 the kernel uses
+// for lanes that own nothing, so those lanes stay out of range for any array size.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long long bytes) {
-  const long long lim = 0xFFFFFFFFll;
+  const long long lim = 0xFFFFFFF0ll;
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0,
                                            (int)(unsigned)(bytes > lim ? lim : bytes), 0x00020000);
 }
@@ -273,7 +275,12 @@ struct Window {
   R MXN[3], MNN[3], U3[3], DW3[3];             // written for column q-2
 };
 
-template <typename R, int LPS, int G>
+// BIG: some array is 4 GiB or larger.  Then every buffer descriptor starts at the first row
+// (level) its wave touches, so the per-lane 32-bit offsets only span the wave's few rows (the
+// column offset, a 32-bit scalar, needs ncrms * (nx+6) * sizeof(R) < 4 GiB).  Otherwise one
+// descriptor per array serves all waves (7 descriptors instead of 3 cost 2 % through scalar
+// register pressure, hence the two instantiations).
+template <typename R, int LPS, int G, bool BIG>
 __global__ void __launch_bounds__(G * LPS, (TileV2<R, LPS, G>::MIN_WAVES))
 mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   using T = TileV2<R, LPS, G>;
@@ -291,17 +298,19 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   // grid = (tracers, instance groups): tracer is the FASTEST block index, so the
   // workgroups that share the same rows of u,w,rho,rhow,adz are dispatched together and
   // all but the first read them from the L2 / Infinity Cache instead of HBM
-  int tr = blockIdx.x;
-  unsigned grp = blockIdx.y;
+  // grid = ntracers * groups workgroups in one dimension, tracer fastest (a.ntracers)
+  const unsigned ntr_ = (unsigned)a.ntracers;
+  int tr = (int)(blockIdx.x % ntr_);
+  unsigned grp = blockIdx.x / ntr_;
 #ifndef MPD2_NO_XCD_TRACERS
   // Tracer batches: workgroups are dealt to the 8 XCDs round-robin in dispatch order, so with
   // the plain mapping the tracers of one instance group land on 8 different L2s.  Re-deal
   // them: all tracers of group g go to XCD g % 8, back to back, and 24 of 25 reads of that
   // group's u, w rows hit in that XCD's L2.
-  if (gridDim.x > 1) {
-    const unsigned ntr = gridDim.x, nxcd = 8;
-    const unsigned L = blockIdx.x + ntr * blockIdx.y;   // dispatch order (x fastest)
-    const unsigned full = (gridDim.y / nxcd) * nxcd;    // groups the re-deal covers
+  if (ntr_ > 1) {
+    const unsigned ntr = ntr_, nxcd = 8;
+    const unsigned L = blockIdx.x;                      // dispatch order
+    const unsigned full = ((gridDim.x / ntr) / nxcd) * nxcd;   // groups the re-deal covers
     if (L < ntr * full) {
       const unsigned xcd = L % nxcd, j = L / nxcd;
       tr = (int)(j % ntr);
@@ -361,11 +370,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   // that own nothing get an out-of-range offset: the buffer range check drops
   // their store, and every wave still issues the same number of stores.
   const unsigned OOB = 0xFFFFFFF8u;
-  const unsigned tf = (t_act && slt_ok) ? (unsigned)((sl_t + ncrms * (long long)(nx + 6) * t_rowc) * RB) : OOB;
+  const long long lvl_f = ncrms * (long long)(nx + 6), lvl_u = ncrms * (long long)(nx + 5),
+                  lvl_w = ncrms * (long long)(nx + 4);           // elements between levels
+  const long long end_f = lvl_f * nzm, end_u = lvl_u * nzm, end_w = lvl_w * nz;  // elements per array
+  const int st_row0 = BIG ? min(wave * (64 / G), nzm - 1) : 0;   // descriptor base row of the wave's stores
+  const unsigned tf = (t_act && slt_ok) ? (unsigned)((sl_t + lvl_f * (t_rowc - st_row0)) * RB) : OOB;
   const unsigned colb = (unsigned)(ncrms * RB);  // bytes between columns
-  const __amdgpu_buffer_rsrc_t rsf = make_rsrc(f, ncrms * (long long)RB * (nx + 6) * nzm);
-  const __amdgpu_buffer_rsrc_t rsu = make_rsrc(a.u, ncrms * (long long)RB * (nx + 5) * nzm);
-  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.w, ncrms * (long long)RB * (nx + 4) * nz);
+  const __amdgpu_buffer_rsrc_t rsf = make_rsrc(f + lvl_f * st_row0, (end_f - lvl_f * st_row0) * RB);
 
   // ---- DMA mapping: one wave instruction moves 256 bytes, 4 per lane = RPI rows of G
   //      elements (128-B rows: two rows, lanes 0-31 row 2j, lanes 32-63 row 2j+1; 256-B rows:
@@ -376,6 +387,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   constexpr int DPE = RB / 4;            // dwords per element
   static_assert(T::NIT * T::NWV * RPI == LPS, "the wave's DMA instructions tile the LPS rows of an array block");
   unsigned vdf[T::NIT], vdu[T::NIT], vdw[T::NIT];  // per-lane source byte offsets of the wave's instructions
+  __amdgpu_buffer_rsrc_t rdf[T::NIT], rdu[T::NIT], rdw[T::NIT];  // ... and their descriptors
   int jd[T::NIT];
 #pragma unroll
   for (int it = 0; it < T::NIT; ++it) {
@@ -384,15 +396,20 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
     // rows beyond nzm (the block has LPS of them) have nothing to fetch: an out-of-range
     // source offset makes the DMA write zeros to that (never read) part of the block
     // without a memory access, and the wave's instruction count stays fixed
+    const int row0 = BIG ? min(j * RPI, nzm - 1) : 0;   // descriptor base row of the instruction
     const int row = j * RPI + lane / LPR;
     const bool row_ok = row < nzm;
     const int p = (lane % LPR) / DPE;
     long long sl_d = sl_base + (p ^ (j & (G - 1)));
     if (sl_d >= ncrms) sl_d = ncrms - 1;
     const unsigned part = (lane % DPE) * 4;
-    vdf[it] = row_ok ? (unsigned)((sl_d + ncrms * (long long)(nx + 6) * row) * RB) + part : OOB;
-    vdu[it] = row_ok ? (unsigned)((sl_d + ncrms * (long long)(nx + 5) * row) * RB) + part : OOB;
-    vdw[it] = row_ok ? (unsigned)((sl_d + ncrms * (long long)(nx + 4) * row) * RB) + part : OOB;
+    const int dr = row_ok ? row - row0 : 0;
+    vdf[it] = row_ok ? (unsigned)((sl_d + lvl_f * dr) * RB) + part : OOB;
+    vdu[it] = row_ok ? (unsigned)((sl_d + lvl_u * dr) * RB) + part : OOB;
+    vdw[it] = row_ok ? (unsigned)((sl_d + lvl_w * dr) * RB) + part : OOB;
+    rdf[it] = make_rsrc(f + lvl_f * row0, (end_f - lvl_f * row0) * RB);
+    rdu[it] = make_rsrc(a.u + lvl_u * row0, (end_u - lvl_u * row0) * RB);
+    rdw[it] = make_rsrc(a.w + lvl_w * row0, (end_w - lvl_w * row0) * RB);
   }
   // compute-side read position inside one array block of a slot
   auto lds_pos = [&](int level) __attribute__((always_inline)) {  // position of (level, this instance)
@@ -420,9 +437,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
 #pragma unroll
     for (int it = 0; it < T::NIT; ++it) {
       R* d = slot + jd[it] * T::EPI;  // 256 bytes per instruction
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdf[it], (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdu[it], (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdw[it], (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, 0);
     }
   };
 

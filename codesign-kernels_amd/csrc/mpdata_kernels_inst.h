@@ -55,8 +55,15 @@ template <typename R, int LPS, int G>
 static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) {
   using T = v2::TileV2<R, LPS, G>;
   const unsigned groups = (unsigned)((a.ncrms + G - 1) / G);
-  dim3 grid((unsigned)ntracers, groups, 1), block(T::THREADS, 1, 1);  // tracer fastest
-  hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G>), grid, block, 0, (hipStream_t)stream, a);
+  MpdataArgsT<R> b = a;
+  b.ntracers = ntracers;
+  dim3 grid((unsigned)ntracers * groups, 1, 1), block(T::THREADS, 1, 1);  // tracer fastest
+  // arrays of 4 GiB or more: the instantiation with per-wave descriptor bases
+  const bool big = (double)a.ncrms * (a.nx + 6) * a.nz * (double)sizeof(R) >= 4294967000.0;
+  if (big)
+    hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, true>), grid, block, 0, (hipStream_t)stream, b);
+  else
+    hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, false>), grid, block, 0, (hipStream_t)stream, b);
 }
 
 int max_tile_id() { return 43; }
@@ -137,7 +144,7 @@ bool launch_f32(int id, const MpdataArgsF32& a, int ntracers, void* stream) {
     p.rhow = reinterpret_cast<const v2::f32x2*>(a.rhow);
     p.adz = reinterpret_cast<const v2::f32x2*>(a.adz);
     p.flux = reinterpret_cast<v2::f32x2*>(a.flux);
-    p.ncrms = a.ncrms / 2; p.nx = a.nx; p.nz = a.nz;
+    p.ncrms = a.ncrms / 2; p.nx = a.nx; p.nz = a.nz; p.ntracers = ntracers;
     p.f_tstride = a.f_tstride / 2; p.flux_tstride = a.flux_tstride / 2;
     p.dbg = a.dbg;
 #define X(ID, LPS_, G_)                                        \

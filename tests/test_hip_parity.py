@@ -236,6 +236,43 @@ def test_full_size_config3_sampled_against_oracle(M, oracle, variant):
             assert max_abs(f, f_ref) < TOL_ABS and max_abs(flux, flux_ref) < TOL_ABS
 
 
+@pytest.mark.parametrize("variant", [0, 1], ids=["exact", "fast"])
+def test_arrays_larger_than_4GiB(M, oracle, variant):
+    """ncrms = 600000: f, u, w are 4.8-4.9 GB each.  The x-marching kernel addresses rows with
+    32-bit offsets relative to per-wave descriptor bases, so it must stay the kernel of choice
+    (the k-marching fallback is 3-8x slower) and stay exact; sampled blocks of instances at the
+    start, across the 4-GiB boundaries of the arrays, and at the end."""
+    import torch
+    ncrms, nx, nz = 600000, 32, 28
+    M.set_variant(variant)
+    M.set_tile(-1)
+    sh = M.shapes(ncrms, nx, nz)
+    d = {k: torch.empty(s, dtype=torch.float64, device="cuda:0") for k, s in sh.items()}
+    assert d["f"].numel() * 8 > 2**32
+    for k in d:
+        M.fill_synthetic(d[k], k, 100, oracle.DIST_CONDITIONED)
+    f0_lo = d["f"][:, 0, :].clone()
+    flux_top = d["flux"][nz - 1].clone()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    M.advect_scalar2D(d["f"], d["u"], d["w"], d["rho"], d["rhow"], d["flux"], d["adz"])
+    ev1.record()
+    torch.cuda.synchronize()
+    assert torch.equal(d["f"][:, 0, :], f0_lo) and torch.equal(d["flux"][nz - 1], flux_top)
+    assert bool(torch.isfinite(d["f"]).all())
+    for s0, n in ((0, 40), (123456 + 3, 37), (299990, 50), (ncrms - 21, 21)):
+        inp = oracle.make_inputs(n, nx, nz, seed=100, dist=oracle.DIST_CONDITIONED, ncrms_global=ncrms, sl0=s0)
+        f_ref, flux_ref = oracle.advect(inp)
+        f = to_host(d["f"][..., s0:s0 + n])
+        flux = to_host(d["flux"][..., s0:s0 + n])
+        if variant == M.VARIANT_EXACT:
+            assert np.array_equal(f, f_ref) and flux_close(flux, flux_ref)
+        else:
+            assert max_abs(f, f_ref) < TOL_ABS and max_abs(flux, flux_ref) < TOL_ABS
+    # the fast kernel, not the fallback: 9.2x the cells of config 3 in well under 9.2 x 1.5 ms
+    assert ev0.elapsed_time(ev1) < 9.2 * 1.5, f"{ev0.elapsed_time(ev1):.2f} ms: k-marching fallback?"
+
+
 def test_sharded_equals_unsharded_bitwise(M, oracle):
     """Two 'ranks' worth of shards on one GPU == the unsharded run."""
     import torch
