@@ -34,6 +34,14 @@ struct BwkArgs {
 };
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+// qtens is read once and written once: BWK_NT marks the stream non-temporal
+#ifdef BWK_NT
+#define BWK_LOAD(p) __builtin_nontemporal_load(reinterpret_cast<const d4*>(p))
+#define BWK_STORE(p, v) __builtin_nontemporal_store((v), reinterpret_cast<d4*>(p))
+#else
+#define BWK_LOAD(p) (*reinterpret_cast<const d4*>(p))
+#define BWK_STORE(p, v) (*reinterpret_cast<d4*>(p) = (v))
+#endif
 
 // value of lane `SRC` of the lane's DPP quad
 template <int SRC>
@@ -86,7 +94,7 @@ __global__ void __launch_bounds__(BWK_THREADS, 2) bwk_kernel(const BwkArgs g) {
   // software pipeline: the loads of pass p+1 are in flight while pass p is computed (a wave
   // moves only 2 KB per pass; without this the chip has too few bytes in flight to fill HBM)
   d4 nxt = d4{0.0, 0.0, 0.0, 0.0};
-  if (slab0 < g.nslab) nxt = *reinterpret_cast<const d4*>(base + slab0 * 16);
+  if (slab0 < g.nslab) nxt = BWK_LOAD(base + slab0 * 16);
   for (int p = 0; p < g.passes; ++p) {
     const long long slab = slab0 + (long long)p * BWK_SLABS_PER_PASS;
     // a quad is whole or not at all inside the element: the DPP broadcasts below stay valid
@@ -94,7 +102,7 @@ __global__ void __launch_bounds__(BWK_THREADS, 2) bwk_kernel(const BwkArgs g) {
     double* const ptr = base + slab * 16;
     const d4 sv = nxt;
     if (p + 1 < g.passes && slab + BWK_SLABS_PER_PASS < g.nslab)
-      nxt = *reinterpret_cast<const d4*>(ptr + BWK_SLABS_PER_PASS * 16);
+      nxt = BWK_LOAD(ptr + BWK_SLABS_PER_PASS * 16);
     const double sc[4] = {sv.x, sv.y, sv.z, sv.w};
 
     // ---- gradient_sphere (:109-134) -----------------------------------------------------
@@ -143,7 +151,7 @@ __global__ void __launch_bounds__(BWK_THREADS, 2) bwk_kernel(const BwkArgs g) {
     BWK_DIV_STEP(2)
     BWK_DIV_STEP(3)
 #undef BWK_DIV_STEP
-    *reinterpret_cast<d4*>(ptr) = d4{out[0], out[1], out[2], out[3]};
+    BWK_STORE(ptr, (d4{out[0], out[1], out[2], out[3]}));
   }
 }
 
