@@ -41,6 +41,10 @@ def parse():
     # leave that transient outside the timed region
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="untimed GPU wake-up before the warm-up steps: scratch launches of the same kernel for "
+                         "about this long, so that the clock / power-state ramp after idle (DESIGN.md 4.4) is "
+                         "over even when --warmup is small; 0 disables")
     ap.add_argument("--ncrms-per-gpu", type=int, default=65536)
     ap.add_argument("--nx", type=int, default=32)
     ap.add_argument("--nz", type=int, default=28)
@@ -241,12 +245,23 @@ ALIGNED = False  # --aligned
 N_SCRATCH = 3  # f buffers the warm-up launches cycle through (their results are not used)
 
 
+PREWARM_MS = 60.0  # --prewarm-ms
+
+
 def timed_run(M, torch, dist_mod, world, d, fs, steps, warmup):
     """fs: min(warmup, N_SCRATCH) scratch buffers for the warm-up launches, followed by one
     pristine f buffer per timed step (the routine works in place)."""
     def step(f):
         M.advect_scalar2D(f, d["u"], d["w"], d["rho"], d["rhow"], d["flux"], d["adz"])
 
+    if PREWARM_MS > 0:   # GPU wake-up on a private scratch copy (not one of the timed buffers)
+        scratch = fs[-1].clone()
+        t_end = time.perf_counter() + PREWARM_MS * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                step(scratch)
+            torch.cuda.synchronize()
+        del scratch
     nscr = min(warmup, N_SCRATCH)
     for i in range(warmup):
         step(fs[i % nscr])
@@ -276,9 +291,10 @@ def timed_run(M, torch, dist_mod, world, d, fs, steps, warmup):
 
 
 def main():
-    global ALIGNED
+    global ALIGNED, PREWARM_MS
     args = parse()
     ALIGNED = args.aligned
+    PREWARM_MS = args.prewarm_ms
     import torch
     import torch.distributed as dist
     import codesign_kernels_amd as M
@@ -342,6 +358,7 @@ def main():
                        "ncrms_per_gpu": n_loc, "ncrms_global": n_glob, "nx": nx, "nz": nz,
                        "ntracers": ntr, "variant": args.variant, "input_law": args.dist,
                        "placement": "aligned" if args.aligned else "f,u,w staggered mod 1 KiB",
+                       "prewarm_ms": args.prewarm_ms,
                        "parallelism": f"ncrms-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
