@@ -8,12 +8,13 @@
 //
 //   * a LANE owns one (CRM instance sl, vertical level k) pair; a wave holds
 //     64/LPS instances x LPS lanes (LPS >= nz, a power of two); the vertical
-//     neighbours kb = max(1,k-1), kc = min(nzm,k+1) (reference :515-516) are
-//     other lanes of the same wave, fetched with ds_bpermute (LDS crossbar, no
-//     memory, no barrier) through per-lane source indices that realise the
-//     clamps; lane k = nz is a "ghost" level holding w = 0, which makes
-//     www(:,:,:,nz) = 0 (:511) fall out of the arithmetic;
-//   * the kernel marches over the x columns q = -2 .. nx+5; the horizontal
+//     neighbours kb = max(1,k-1), kc = min(nzm,k+1) (reference :515-516) are the
+//     adjacent lanes: derived quantities come by DPP (wave_shr / wave_shl, the
+//     clamps fused into the move as v_cndmask_b32_dpp), raw inputs by extra LDS
+//     reads with the clamp in the address; lane k = nz is a "ghost" level holding
+//     w = 0, which makes www(:,:,:,nz) = 0 (:511) fall out of the arithmetic;
+//   * the kernel marches over the x columns q = -2 .. nx+3 (+ one epilogue that
+//     writes back the last three columns); the horizontal
 //     dependencies (radius 3) become a 3-column
 //     software pipeline in registers:
 //         step q:  upwind fluxes of column q, first-pass f1 of column q-1,
@@ -33,9 +34,15 @@
 //     tile (row stride 17 doubles) and full-row stores.  Every step issues the
 //     same number of vector-memory operations per wave (1 store + 6 DMA), so
 //     one counted s_waitcnt vmcnt(14) + a raw s_barrier per step is the only
-//     synchronisation and three columns stay in flight across it;
+//     synchronisation and three columns stay in flight across it; the step's
+//     vector-memory instructions are issued at its end;
 //   * irho, iadz, irhow, dd (:552-553,:565,:569) depend on (sl,k) only and are
 //     computed ONCE per lane, not once per column.
+//
+// The kernel is a template over the type R a lane computes in -- double, float, or
+// float2 = two adjacent instances per lane (packed fp32 arithmetic, the fp64
+// kernel's data movement) -- and over BIG (arrays of 4 GiB or more: per-wave
+// descriptor bases).  DESIGN.md sections 4.1, 4.4, 4.5 have the measurements.
 //
 // f is bit-identical to the reference in the EXACT build.  flux(k) is
 // accumulated per lane as (sum_i upwind) + (sum_i limited), each sum in the
