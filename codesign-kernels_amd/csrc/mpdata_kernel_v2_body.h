@@ -133,6 +133,13 @@ __device__ __forceinline__ f32x2 recip_nr(f32x2 d) {
 }
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// cache-policy bits of the row stores / DMA loads (experiments: 2 = nt)
+#ifndef MPD2_ST_AUX
+#define MPD2_ST_AUX 0
+#endif
+#ifndef MPD2_LD_AUX
+#define MPD2_LD_AUX 0
+#endif
 // Buffer addressing for the row transfers: wave-uniform descriptor + per-lane
 // 32-bit byte offset (VGPR) + wave-uniform byte offset of the column (SGPR).
 // The range (num_records) is clipped BELOW the out-of-range marker 0xFFFFFFF8 the kernel uses
@@ -146,7 +153,7 @@ __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 #ifdef MPD2_ABL_NOMEM  // timing ablation only (wrong results)
   if (v != 1.2345e300) return;
 #endif
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, MPD2_ST_AUX);
 }
 __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x2 v) {
 #ifdef MPD2_ABL_NOMEM
@@ -444,9 +451,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
 #pragma unroll
     for (int it = 0; it < T::NIT; ++it) {
       R* d = slot + jd[it] * T::EPI;  // 256 bytes per instruction
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdf[it], (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdu[it], (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdw[it], (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdf[it], (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, MPD2_LD_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdu[it], (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, MPD2_LD_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdw[it], (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, MPD2_LD_AUX);
     }
   };
 
