@@ -112,6 +112,23 @@ def cpu_baseline(nx, nz):
     return out
 
 
+def copy_ceiling(torch, dev):
+    """Measured device-to-device copy rate of this box ('also record a measured
+    device-copy ceiling'): torch copy of a 538-MB buffer (the size of f), read + write bytes."""
+    n = 65536 * 38 * 27
+    a = torch.empty(n, dtype=torch.float64, device=dev).fill_(1.0)
+    b = torch.empty_like(a)
+    for _ in range(10):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(30):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2 * n * 8 / (e0.elapsed_time(e1) / 30 * 1e-3) / 1e9
+
+
 def bench_bwk(torch, dev, steps, warmup, with_cpu):
     """Side measurement of the second kernel: biharmonic_wk_scalar on a
     cubed-sphere ne=30 mesh (5400 elements x 72 levels x 40 tracers, 2 GB of qtens), FAST
@@ -368,6 +385,12 @@ def main():
                          "kernel_ms_median": statistics.median(kms),
                          "cell_updates_per_sec_kernel": n_loc * nx * (nz - 1) * ntr / (k_avg * 1e-3)},
         }
+
+    if rank == 0:
+        try:
+            result["roofline"]["measured_copy_GBs"] = copy_ceiling(torch, dev)
+        except Exception:
+            result["roofline"]["measured_copy_GBs"] = None
 
     # ---- side measurement: tracer-batched variant (configs[3]/[4]) -----------
     if not args.no_batched and ntr == 1:
