@@ -302,7 +302,7 @@ def timed_run(M, torch, dist_mod, world, d, fs, steps, warmup):
     dt = time.perf_counter() - t0
     kms = [a.elapsed_time(b) for a, b in ev]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist_mod.get_backend() == "nccl" else "cpu")
         dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
         dt = float(t.item())
     return dt, kms
@@ -327,10 +327,18 @@ def main():
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # MPDATA_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- exercises the N > 1
+    # control flow on a one-GPU box (RCCL refuses two ranks on one device); numbers are meaningless
+    rehearsal = os.environ.get("MPDATA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     M.set_variant(M.VARIANT_FAST if args.variant == "fast" else M.VARIANT_EXACT)
     M.set_tile(args.tile)

@@ -1,0 +1,29 @@
+"""The N > 1 control flow of bench.py (barriers, max-over-ranks time, rank-0 JSON line) rehearsed
+with two processes.  RCCL refuses two ranks on one device, so the rehearsal mode puts both ranks
+on cuda:0 over gloo (MPDATA_BENCH_REHEARSAL=1); the numbers mean nothing, the plumbing is the
+same code the driver runs with --gpus N."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_prints_one_whole_job_line():
+    env = dict(os.environ, MPDATA_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--ncrms-per-gpu", "4096",
+           "--no-batched", "--no-fp32", "--no-bwk", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["ncrms_global"] == 2 * 4096
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
