@@ -21,7 +21,10 @@
 
 namespace BWK_NS {
 
-constexpr int BWK_THREADS = 256;          // 4 waves = 64 slabs per workgroup pass
+#ifndef BWK_THREADS_N
+#define BWK_THREADS_N 256
+#endif
+constexpr int BWK_THREADS = BWK_THREADS_N;  // 4 waves = 64 slabs per workgroup pass
 constexpr int BWK_SLABS_PER_PASS = BWK_THREADS / 4;
 
 struct BwkArgs {
