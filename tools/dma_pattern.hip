@@ -11,7 +11,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)(unsigned)bytes, 0x00020000);
 }
 // G = instances per workgroup (row segment = 8*G bytes), DW = bytes per lane of one DMA
-template <int G, int DW, int THREADS = 512>
+template <int G, int DW, int THREADS = 512, bool BLK = false>
 __global__ void __launch_bounds__(THREADS) skel(const double* f, const double* u, const double* w, double* fo,
                                             long long ncrms, int nx, int nzm) {
   // gridDim.x < number of groups: persistent workgroups, each sweeps several groups one
@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(THREADS) skel(const double* f, const double* u
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long sl0 = grp * G;
-  const unsigned colb = (unsigned)(ncrms * 8);
+  const unsigned colb = BLK ? (unsigned)(nzm * G * 8) : (unsigned)(ncrms * 8);
   const __amdgpu_buffer_rsrc_t rsf = make_rsrc(f, ncrms * 8ll * (nx + 6) * nzm);
   const __amdgpu_buffer_rsrc_t rsu = make_rsrc(u, ncrms * 8ll * (nx + 6) * nzm);
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(w, ncrms * 8ll * (nx + 6) * nzm);
@@ -40,7 +40,9 @@ __global__ void __launch_bounds__(THREADS) skel(const double* f, const double* u
     arr[it] = j / (32 / RPI); blk[it] = j % (32 / RPI);
     const int lanes_per_row = ROWB / DW;
     int row = blk[it] * RPI + lane / lanes_per_row; if (row > nzm - 1) row = nzm - 1;
-    voff[it] = (unsigned)((sl0 + ncrms * (long long)(nx + 6) * row) * 8) + (lane % lanes_per_row) * DW;
+    // BLK: the arrays are stored [group][column][row][G] (a workgroup's bytes are contiguous)
+    voff[it] = BLK ? (unsigned)(((grp * (nx + 6)) * nzm + row) * (long long)G * 8 % 4000000000ll) + (lane % lanes_per_row) * DW
+                   : (unsigned)((sl0 + ncrms * (long long)(nx + 6) * row) * 8) + (lane % lanes_per_row) * DW;
   }
   // store mapping: thread -> (row, instance)
   constexpr int NST = (32 * G + THREADS - 1) / THREADS;  // row stores per thread and step
@@ -51,7 +53,9 @@ __global__ void __launch_bounds__(THREADS) skel(const double* f, const double* u
   for (int i = 0; i < NST; ++i) {
     t_row[i] = tid / G + i * (THREADS / G);
     const bool act = t_row[i] < nzm;
-    tf[i] = act ? (unsigned)((sl0 + t_sl + ncrms * (long long)(nx + 6) * t_row[i]) * 8) : 0xFFFFFFF8u;
+    tf[i] = !act ? 0xFFFFFFF8u
+            : BLK ? (unsigned)((((grp * (nx + 6)) * nzm + t_row[i]) * (long long)G + t_sl) * 8 % 4000000000ll)
+                  : (unsigned)((sl0 + t_sl + ncrms * (long long)(nx + 6) * t_row[i]) * 8);
     if (!act) t_row[i] = 0;
   }
   auto dma = [&](int col) __attribute__((always_inline)) {
@@ -91,18 +95,18 @@ __global__ void __launch_bounds__(THREADS) skel(const double* f, const double* u
   __builtin_amdgcn_s_barrier();
   }
 }
-template <int G, int DW, int THREADS = 512>
+template <int G, int DW, int THREADS = 512, bool BLK = false>
 void run(const double* f, const double* u, const double* w, double* fo, long long ncrms, int nx, int nzm, int persist = 0) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int blocks = persist ? persist : (int)(ncrms / G);
   for (int r = 0; r < 60; ++r)  // warm-up: the first ~30 ms after idle run 5-10 % slow
-    hipLaunchKernelGGL((skel<G, DW, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, f, u, w, fo, ncrms, nx, nzm);
+    hipLaunchKernelGGL((skel<G, DW, THREADS, BLK>), dim3(blocks), dim3(THREADS), 0, 0, f, u, w, fo, ncrms, nx, nzm);
   hipEventRecord(e0);
-  for (int r = 0; r < 60; ++r) hipLaunchKernelGGL((skel<G, DW, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, f, u, w, fo, ncrms, nx, nzm);
+  for (int r = 0; r < 60; ++r) hipLaunchKernelGGL((skel<G, DW, THREADS, BLK>), dim3(blocks), dim3(THREADS), 0, 0, f, u, w, fo, ncrms, nx, nzm);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 60;
   const double bytes = (double)ncrms * nzm * (nx + 6) * 8.0 * 4;  // 3 reads + 1 write
-  printf("threads %4d blocks %5d G=%2d (%3d-B rows) DMA %2d B/lane: %.3f ms  %.2f TB/s (err %d)\n", THREADS, blocks, G, G * 8, DW, ms, bytes / (ms * 1e-3) / 1e12, (int)hipGetLastError());
+  printf("%s threads %4d blocks %5d G=%2d (%3d-B rows) DMA %2d B/lane: %.3f ms  %.2f TB/s (err %d)\n", BLK ? "BLOCKED" : "       ", THREADS, blocks, G, G * 8, DW, ms, bytes / (ms * 1e-3) / 1e12, (int)hipGetLastError());
 }
 int main(int argc, char** argv) {
   // argv[1] = 1: stagger the arrays by 256 B each (different offsets modulo 1 KiB)
@@ -124,6 +128,11 @@ int main(int argc, char** argv) {
     run<16, 4>(f, u, w, f, ncrms, nx, nzm);
     run<32, 4>(f, u, w, f, ncrms, nx, nzm);
     run<32, 16>(f, u, w, f, ncrms, nx, nzm);
+    printf("blocked layout [group][column][row][G], separate output and in place:\n");
+    run<16, 4, 512, true>(f, u, w, fo, ncrms, nx, nzm);
+    run<16, 16, 512, true>(f, u, w, fo, ncrms, nx, nzm);
+    run<16, 4, 512, true>(f, u, w, f, ncrms, nx, nzm);
+    run<32, 16, 512, true>(f, u, w, f, ncrms, nx, nzm);
     printf("1024-thread workgroups:\n");
     run<32, 4, 1024>(f, u, w, fo, ncrms, nx, nzm);
     run<32, 16, 1024>(f, u, w, fo, ncrms, nx, nzm);
