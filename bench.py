@@ -64,8 +64,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the 25-tracer side measurement")
     ap.add_argument("--batched-tracers", type=int, default=25)
-    ap.add_argument("--scatter", action="store_true",
-                    help="also time the RCCL scatter/gather of a small problem (outside the timed region)")
+    ap.add_argument("--batched-steps", type=int, default=20, help="timed steps of the 25-tracer block (at most --steps)")
+    ap.add_argument("--no-scatter", action="store_true", help="N > 1: skip the scatter/gather measurement")
+    ap.add_argument("--no-reflayout", action="store_true",
+                    help="skip the side measurement of the reference-layout device call (x-march kernel)")
+    ap.add_argument("--layout", choices=["wavemajor", "reference"], default="wavemajor",
+                    help="device layout of the plans the headline runs on (include/mpdata_hip.h section 3)")
     return ap.parse_args()
 
 
@@ -235,56 +239,43 @@ def _timeit(fn):
     return time.perf_counter() - t0
 
 
-def make_problem(M, torch, dev, ncrms_loc, ncrms_glob, sl0, nx, nz, ntr, nbuf, dist, dtype=None):
-    dtype = torch.float64 if dtype is None else dtype
-    sh = M.shapes(ncrms_loc, nx, nz, ntr)
-    # arrays placed as INTEGRATION.md advises a caller to: f, u, w at different offsets modulo
-    # 1 KiB (HBM channel interleave); --aligned reproduces equally aligned bases instead
+def make_shared(M, torch, dev, ncrms_loc, ncrms_glob, sl0, nx, nz, dist, dtype):
+    """u, w, rho, rhow, adz, flux of one rank in the reference layout, generated on the device."""
+    sh = M.shapes(ncrms_loc, nx, nz, 1)
     alloc = (lambda shape, k: torch.empty(shape, dtype=dtype, device=dev)) if ALIGNED else \
             (lambda shape, k: M.empty_staggered(shape, k, dtype, dev))
     d = {k: alloc(sh[k], k) for k in ("u", "w", "rho", "rhow", "adz", "flux")}
     for k in d:
         M.fill_synthetic(d[k], k, 100, dist, ncrms_global=ncrms_glob, sl0=sl0)
-    fs = []
-    for b in range(nbuf):
-        f = alloc(sh["f"], "f")
-        # per-tracer / per-buffer seeds: distinct data, same law
-        if ntr == 1:
-            M.fill_synthetic(f, "f", 100 + b, dist, ncrms_global=ncrms_glob, sl0=sl0)
-        else:
-            for t in range(ntr):
-                M.fill_synthetic(f[t], "f", 100 + b * ntr + t, dist, ncrms_global=ncrms_glob, sl0=sl0)
-        fs.append(f)
-    return d, fs
+    return d, alloc, sh
 
 
-ALIGNED = False  # --aligned
-N_SCRATCH = 3  # f buffers the warm-up launches cycle through (their results are not used)
-
-
+ALIGNED = False  # --aligned (reference-layout side measurement only)
+N_SCRATCH = 3    # field buffers the warm-up launches cycle through (their results are not used)
 PREWARM_MS = 60.0  # --prewarm-ms
+# VALU instructions one wave executes per call at nx=32, nz=28 (rocprofv3 SQ_INSTS_VALU / SQ_WAVES,
+# profiles/r02_pmc_summary.json) and the measured fp64 VALU issue peak of the chip
+# (tools/valu_rate.hip: 33e12 lane-ops/s = 515.6e9 wave-instructions/s)
+VALU_PER_WAVE_NX32_NZ28 = {"fast": 4305.0, "exact": None}
+VALU_PEAK_WAVE_INSTR_PER_S = 33.0e12 / 64.0
 
 
-def timed_run(M, torch, dist_mod, world, d, fs, steps, warmup):
-    """fs: min(warmup, N_SCRATCH) scratch buffers for the warm-up launches, followed by one
-    pristine f buffer per timed step (the routine works in place)."""
-    def step(f):
-        M.advect_scalar2D(f, d["u"], d["w"], d["rho"], d["rhow"], d["flux"], d["adz"])
+def free_bytes(torch):
+    return torch.cuda.mem_get_info()[0]
 
-    if PREWARM_MS > 0:   # GPU wake-up on a private scratch copy (not one of the timed buffers)
-        scratch = torch.empty_like(fs[-1]) if ALIGNED else M.empty_staggered(fs[-1].shape, "f", fs[-1].dtype, fs[-1].device)
-        scratch.copy_(fs[-1])
+
+def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=None):
+    """W untimed warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier +
+    synchronize; per-step HIP events on the launch stream.  Returns (max-over-ranks wall seconds,
+    per-step kernel ms)."""
+    if PREWARM_MS > 0 and prewarm_launch is not None:   # GPU wake-up (clock / power-state ramp)
         t_end = time.perf_counter() + PREWARM_MS * 1e-3
         while time.perf_counter() < t_end:
             for _ in range(8):
-                step(scratch)
+                prewarm_launch()
             torch.cuda.synchronize()
-        del scratch
-    nscr = min(warmup, N_SCRATCH)
     for i in range(warmup):
-        step(fs[i % nscr])
-    fs = fs[nscr:]
-    warmup = 0
+        launch(-1 - i)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     torch.cuda.synchronize()
     if world > 1:
@@ -293,7 +284,7 @@ def timed_run(M, torch, dist_mod, world, d, fs, steps, warmup):
     t0 = time.perf_counter()
     for i in range(steps):
         ev[i][0].record()
-        step(fs[warmup + i])
+        launch(i)
         ev[i][1].record()
     torch.cuda.synchronize()
     if world > 1:
@@ -308,11 +299,71 @@ def timed_run(M, torch, dist_mod, world, d, fs, steps, warmup):
     return dt, kms
 
 
+def bench_plan(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup,
+               dist_law, np_dtype, tdt, mem_frac=0.55):
+    """The hot path behind the plan API (device state in the library's own layout,
+    include/mpdata_hip.h section 3): one step = one run of `ntr` tracers on a field set of its
+    own.  As many pristine field sets as the steps need are created if they fit in `mem_frac` of
+    the free memory; otherwise the timed steps cycle through the sets (noted in the result)."""
+    eb = 8 if tdt == torch.float64 else 4
+    set_bytes = n_loc * (nx + 6) * (nz - 1) * eb * ntr
+    want = steps + min(warmup, N_SCRATCH)
+    nset = int(max(2, min(want, (free_bytes(torch) * mem_frac) // set_bytes)))
+    plan = M.Plan(n_loc, nx, nz, nset * ntr, dtype=np_dtype)
+    plan.set_stream()
+    plan.import_device(None, shared["u"], shared["w"], shared["rho"], shared["rhow"], shared["adz"], None)
+    ftmp = torch.empty(shape_f, dtype=tdt, device=dev)
+    t0 = time.perf_counter()
+    for t in range(nset * ntr):     # per-tracer / per-set seeds: distinct data, same law
+        M.fill_synthetic(ftmp, "f", 100 + t, dist_law, ncrms_global=n_glob, sl0=sl0)
+        plan.import_device(ftmp, flux=shared["flux"], first_tracer=t)
+    torch.cuda.synchronize()
+    t_import = time.perf_counter() - t0
+    del ftmp
+    nscr = min(max(warmup, 1), N_SCRATCH, nset - 1)
+    ntimed = nset - nscr
+
+    def launch(i):
+        s = (nset - 1 - ((-1 - i) % nscr)) if i < 0 else (i % ntimed)   # warm-up: the scratch sets
+        plan.run(s * ntr, ntr)
+
+    dt, kms = timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=lambda: launch(-1))
+    info = {"layout": "wave-major (plan-private)" if plan.layout == M.LAYOUT_WAVEMAJOR else "reference",
+            "field_sets": ntimed, "steps_per_field_set": -(-steps // ntimed),
+            "import_s_per_tracer": t_import / (nset * ntr)}
+    plan.close()
+    torch.cuda.empty_cache()
+    return dt, kms, info
+
+
+def roofline_block(alg_bytes, kms, extra=None):
+    k_avg = sum(kms) / len(kms)
+    ach = alg_bytes / (k_avg * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": k_avg,
+         "kernel_ms_min": min(kms), "kernel_ms_median": statistics.median(kms)}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def traffic_lookup(key):
+    """HBM bytes per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 +
+    WRITE_SIZE as the guide prescribes), measured on the builder's box for exactly this kernel and
+    size -- a recorded profile value, not a live measurement (`traffic_source` says so)."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        return json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def main():
     global ALIGNED, PREWARM_MS
     args = parse()
     ALIGNED = args.aligned
     PREWARM_MS = args.prewarm_ms
+    import numpy as np
     import torch
     import torch.distributed as dist
     import codesign_kernels_amd as M
@@ -342,101 +393,148 @@ def main():
 
     M.set_variant(M.VARIANT_FAST if args.variant == "fast" else M.VARIANT_EXACT)
     M.set_tile(args.tile)
+    if args.layout == "reference":
+        M.set_plan_layout(M.LAYOUT_REFERENCE)
     nx, nz = args.nx, args.nz
     n_loc = args.ncrms_per_gpu
     n_glob = n_loc * world
     sl0 = rank * n_loc
     steps, warmup = args.steps, args.warmup
+    mem_frac = 0.55 / (world if rehearsal else 1)
 
-    # ---- headline: 1 tracer (or --tracers) ---------------------------------
     ntr = args.tracers
     f32 = args.dtype == "f32"
     tdt = torch.float32 if f32 else torch.float64
-    d, fs = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, ntr, steps + min(warmup, N_SCRATCH), args.dist, tdt)
-    dt, kms = timed_run(M, torch, dist, world, d, fs, steps, warmup)
-    cells_per_step = n_glob * nx * (nz - 1) * ntr
-    value = cells_per_step * steps / dt
+    npdt = np.float32 if f32 else np.float64
+    shared, alloc, sh = make_shared(M, torch, dev, n_loc, n_glob, sl0, nx, nz, args.dist, tdt)
+    sh_f1 = M.shapes(n_loc, nx, nz, 1)["f"]
+    cells_1 = n_glob * nx * (nz - 1)
+
+    # ---- headline: configs[2] per GPU through the plan API -----------------------------------
+    dt, kms, info = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, ntr, steps,
+                               warmup, args.dist, npdt, tdt, mem_frac)
+    value = cells_1 * ntr * steps / dt
     alg_bytes = M.algorithmic_bytes(n_loc, nx, nz, ntr, f32=f32)  # per launch (one GPU)
-    k_avg = sum(kms) / len(kms)
-    achieved = alg_bytes / (k_avg * 1e-3) / 1e9
-    del fs
-    torch.cuda.empty_cache()
 
     result = None
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t{ntr}" + ("_f32" if f32 else "")
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t{ntr}" + ("_f32" if f32 else "") + \
+              ("_wm" if info["layout"].startswith("wave") else "")
+        traffic = traffic_lookup(key)
         result = {
-            "metric": "advected cell-updates/sec, MPDATA advect_scalar2D (ncrms=65536 per GPU, nx=32, nz=28)",
+            "metric": f"advected cell-updates/sec, MPDATA advect_scalar2D (ncrms={n_loc} per GPU, nx={nx}, nz={nz})",
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[2]: ncrms={n_loc}/GPU (global {n_glob}) nx={nx} "
                                    f"nz={nz} {'fp32 (NOT the headline precision)' if f32 else 'fp64'} "
-                                   f"tracers={ntr}, device-resident, in-place f",
+                                   f"tracers={ntr}, device-resident in a plan (include/mpdata_hip.h 3), in-place f",
                        "ncrms_per_gpu": n_loc, "ncrms_global": n_glob, "nx": nx, "nz": nz,
                        "ntracers": ntr, "variant": args.variant, "input_law": args.dist,
-                       "placement": "aligned" if args.aligned else "f,u,w staggered mod 1 KiB",
+                       "device_layout": info["layout"], "field_sets": info["field_sets"],
+                       "steps_per_field_set": info["steps_per_field_set"],
                        "prewarm_ms": args.prewarm_ms,
                        "parallelism": f"ncrms-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_ms_avg": k_avg, "kernel_ms_min": min(kms),
-                         "kernel_ms_median": statistics.median(kms),
-                         "cell_updates_per_sec_kernel": n_loc * nx * (nz - 1) * ntr / (k_avg * 1e-3)},
+            "roofline": roofline_block(alg_bytes, kms, {
+                "traffic": traffic,
+                "traffic_source": None if traffic is None else "profiles/hbm_traffic.json[%s]: PMC passes of "
+                                  "tools/profile_round.sh on the builder's box, not measured in this run" % key,
+                "cell_updates_per_sec_kernel": n_loc * nx * (nz - 1) * ntr / (sum(kms) / len(kms) * 1e-3)}),
+            "layout_conversion": {"import_ms_per_tracer_incl_fill": info["import_s_per_tracer"] * 1e3,
+                                  "note": "reference layout -> plan layout, on the device, outside the timed region "
+                                          "(like the reference's `!$acc update device`, :107)"},
         }
-
-    if rank == 0:
         try:
-            result["roofline"]["measured_copy_GBs"] = copy_ceiling(torch, dev)
+            c = copy_ceiling(torch, dev)
+            result["roofline"]["measured_copy_GBs"] = c
+            result["roofline"]["frac_of_measured_copy"] = result["roofline"]["achieved"] / c
         except Exception:
             result["roofline"]["measured_copy_GBs"] = None
 
-    # ---- side measurement: tracer-batched variant (configs[3]/[4]) -----------
+    # ---- BASELINE configs[3] / [4]: 25 tracers per instance, every rank ---------------------
     if not args.no_batched and ntr == 1:
         bt = args.batched_tracers
-        bsteps, bwarm = min(steps, 5), min(warmup, 2)
-        d2, fs2 = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, bt, bsteps + min(bwarm, N_SCRATCH), args.dist, tdt)
-        dt2, kms2 = timed_run(M, torch, dist, world, d2, fs2, bsteps, bwarm)
+        bsteps, bwarm = min(steps, args.batched_steps), min(warmup, 2)
+        dt2, kms2, info2 = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, bt,
+                                      bsteps, bwarm, args.dist, npdt, tdt, mem_frac)
         if rank == 0:
             ab = M.algorithmic_bytes(n_loc, nx, nz, bt, f32=f32)
             ka = sum(kms2) / len(kms2)
+            key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t{bt}" + ("_f32" if f32 else "") + \
+                  ("_wm" if info2["layout"].startswith("wave") else "")
+            tr2 = traffic_lookup(key)
+            rb = roofline_block(ab, kms2, {"traffic": tr2, "traffic_source": None if tr2 is None else
+                                           "profiles/hbm_traffic.json[%s] (recorded profile, not this run)" % key})
+            rb["hbm_frac"] = rb["frac"]
+            vpw = VALU_PER_WAVE_NX32_NZ28.get(args.variant) if (nx, nz) == (32, 28) and not f32 else None
+            if vpw:   # second ceiling (SURVEY.md 7 hard part 3): fp64 VALU issue
+                waves = -(-n_loc // 2) * bt
+                t_valu = waves * vpw / VALU_PEAK_WAVE_INSTR_PER_S
+                rb["valu_frac"] = t_valu / (ka * 1e-3)
+                rb["valu_note"] = "VALU instructions per launch (profiles/r02_pmc_summary.json) / measured fp64 VALU " \
+                                  "issue peak (tools/valu_rate.hip, 33e12 lane-ops/s) / kernel time"
             result["tracer_batched"] = {
-                "workload": f"BASELINE.json configs[3]: ncrms={n_loc}/GPU, {bt} tracers sharing u,w,rho,rhow,adz",
-                "value": n_glob * nx * (nz - 1) * bt * bsteps / dt2, "unit": "cell-updates/s",
-                "steps": bsteps, "ms_per_step": dt2 / bsteps * 1e3,
-                "roofline": {"bound": "hbm", "achieved": ab / (ka * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": ab / (ka * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": ab, "kernel_ms_avg": ka}}
-        del fs2, d2
+                "workload": f"BASELINE.json configs[{3 if world == 1 else 4}]: ncrms={n_loc}/GPU (global {n_glob}), "
+                            f"{bt} tracers sharing u,w,rho,rhow,adz, plan API",
+                "value": cells_1 * bt * bsteps / dt2, "unit": "cell-updates/s", "n_gpus": world,
+                "steps": bsteps, "ms_per_step": dt2 / bsteps * 1e3, "field_sets": info2["field_sets"],
+                "steps_per_field_set": info2["steps_per_field_set"], "device_layout": info2["layout"],
+                "roofline": rb}
+
+    # ---- side measurement: the reference-layout device call (x-march kernel): what a caller
+    #      gets whose device arrays stay in the reference layout -------------------------------
+    if not args.no_reflayout and ntr == 1:
+        nb = min(steps + N_SCRATCH, 24)
+        fs = []
+        for b in range(nb):
+            f = alloc(sh["f"], "f")
+            M.fill_synthetic(f, "f", 100 + b, args.dist, ncrms_global=n_glob, sl0=sl0)
+            fs.append(f)
+
+        def launch_ref(i):
+            M.advect_scalar2D(fs[i % nb], shared["u"], shared["w"], shared["rho"], shared["rhow"], shared["flux"], shared["adz"])
+
+        rsteps = min(steps, 40)
+        dt4, kms4 = timed_loop(torch, dist, world, launch_ref, rsteps, min(warmup, 20))
+        if rank == 0:
+            key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t1" + ("_f32" if f32 else "")
+            tr4 = traffic_lookup(key)
+            result["reference_layout_device_call"] = {
+                "workload": f"mpdata_advect_scalar2d{'_f32' if f32 else ''}_device on reference-layout device arrays "
+                            f"(x-march kernel), ncrms={n_loc}/GPU, 1 tracer",
+                "value": cells_1 * rsteps / dt4, "unit": "cell-updates/s", "steps": rsteps,
+                "ms_per_step": dt4 / rsteps * 1e3,
+                "roofline": roofline_block(alg_bytes, kms4, {"traffic": tr4, "traffic_source": None if tr4 is None else
+                                                             "profiles/hbm_traffic.json[%s] (recorded profile)" % key})}
+        del fs
         torch.cuda.empty_cache()
 
     # ---- side measurement: the same workload in fp32 (reference precision switch) ------
     if not args.no_fp32 and not f32 and ntr == 1:
-        d3, fs3 = make_problem(M, torch, dev, n_loc, n_glob, sl0, nx, nz, 1, steps + min(warmup, N_SCRATCH), args.dist, torch.float32)
-        dt3, kms3 = timed_run(M, torch, dist, world, d3, fs3, steps, warmup)
+        sh32, alloc32, _ = make_shared(M, torch, dev, n_loc, n_glob, sl0, nx, nz, args.dist, torch.float32)
+        nb = min(steps + N_SCRATCH, 24)
+        fs3 = []
+        for b in range(nb):
+            f = alloc32(sh["f"], "f")
+            M.fill_synthetic(f, "f", 100 + b, args.dist, ncrms_global=n_glob, sl0=sl0)
+            fs3.append(f)
+
+        def launch32(i):
+            M.advect_scalar2D(fs3[i % nb], sh32["u"], sh32["w"], sh32["rho"], sh32["rhow"], sh32["flux"], sh32["adz"])
+
+        s3 = min(steps, 40)
+        dt3, kms3 = timed_loop(torch, dist, world, launch32, s3, min(warmup, 20))
         if rank == 0:
             ab = M.algorithmic_bytes(n_loc, nx, nz, 1, f32=True)
-            ka = sum(kms3) / len(kms3)
             result["fp32"] = {
-                "workload": f"ncrms={n_loc}/GPU nx={nx} nz={nz} fp32, 1 tracer (mpdata_advect_scalar2d_f32_device)",
-                "value": n_glob * nx * (nz - 1) * steps / dt3, "unit": "cell-updates/s", "steps": steps,
-                "ms_per_step": dt3 / steps * 1e3,
-                "roofline": {"bound": "hbm", "achieved": ab / (ka * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": ab / (ka * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": ab, "kernel_ms_avg": ka}}
-        del fs3, d3
+                "workload": f"ncrms={n_loc}/GPU nx={nx} nz={nz} fp32, 1 tracer (mpdata_advect_scalar2d_f32_device, "
+                            "reference layout)",
+                "value": cells_1 * s3 / dt3, "unit": "cell-updates/s", "steps": s3,
+                "ms_per_step": dt3 / s3 * 1e3, "roofline": roofline_block(ab, kms3)}
+        del fs3, sh32
         torch.cuda.empty_cache()
 
-    # ---- side measurement: the second kernel, rank 0 only -------------------
+    # ---- side measurement: the second / third kernel, rank 0 only ----------
     if not args.no_bwk and rank == 0 and not f32 and ntr == 1:
         try:
             result["biharmonic_wk"] = bench_bwk(torch, dev, min(steps, 50), min(warmup, 50),
@@ -450,31 +548,16 @@ def main():
             result["high_order_flux"] = {"error": repr(exc)}
         torch.cuda.empty_cache()
 
-    # ---- optional: scatter/gather over RCCL (outside any timed region) ------
-    if args.scatter and world > 1:
-        ns = 4096 * world
-        names = ("adz", "f", "u", "w", "rho", "rhow", "flux")
-        sh = M.shapes(ns, nx, nz)
-        if rank == 0:
-            full = {k: torch.empty(sh[k], dtype=torch.float64, device=dev) for k in names}
-            for k in names:
-                M.fill_synthetic(full[k], k, 100, 1)
-            arg = full
-        else:
-            arg = {k: sh[k][:-1] for k in names}
-        torch.cuda.synchronize(); dist.barrier()
-        t0 = time.perf_counter()
-        mine = M.scatter_inputs(arg, ns, src=0, device=dev)
-        torch.cuda.synchronize(); dist.barrier()
-        t_sc = time.perf_counter() - t0
-        M.advect_scalar2D(mine["f"], mine["u"], mine["w"], mine["rho"], mine["rhow"], mine["flux"], mine["adz"])
-        torch.cuda.synchronize(); dist.barrier()
-        t0 = time.perf_counter()
-        M.gather_outputs({"f": mine["f"], "flux": mine["flux"]}, full if rank == 0 else None, ns, dst=0)
-        torch.cuda.synchronize(); dist.barrier()
-        t_ga = time.perf_counter() - t0
-        if rank == 0:
-            result["scatter_gather"] = {"ncrms": ns, "scatter_s": t_sc, "gather_s": t_ga}
+    # ---- N > 1: scatter / gather of a root-resident problem over RCCL (outside any timed
+    #      compute region): ncrms = ncrms_per_gpu * N, one tracer -------------------------------
+    if world > 1 and not args.no_scatter:
+        try:
+            result_sg = bench_scatter_gather(M, torch, dist, world, rank, dev, n_loc, nx, nz)
+            if rank == 0:
+                result["scatter_gather"] = result_sg
+        except Exception as exc:
+            if rank == 0:
+                result["scatter_gather"] = {"error": repr(exc)}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -483,6 +566,41 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_scatter_gather(M, torch, dist, world, rank, dev, n_loc, nx, nz):
+    """Root (rank 0) holds the reference-layout arrays of the global problem; every rank receives
+    its contiguous ncrms block (pack kernel -> grouped send/recv = ncclSend/ncclRecv over xGMI ->
+    contiguous shard), advects it, and the outputs f, flux are gathered back.  Reports seconds and
+    GB/s per peer link (every peer has its own xGMI link to the root)."""
+    ns = n_loc * world
+    names = ("adz", "f", "u", "w", "rho", "rhow", "flux")
+    sh = M.shapes(ns, nx, nz)
+    if rank == 0:
+        full = {k: torch.empty(sh[k], dtype=torch.float64, device=dev) for k in names}
+        for k in names:
+            M.fill_synthetic(full[k], k, 100, 1)
+        arg = full
+    else:
+        full = None
+        arg = {k: sh[k][:-1] for k in names}
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    mine = M.scatter_inputs(arg, ns, src=0, device=dev)
+    torch.cuda.synchronize(); dist.barrier()
+    t_sc = time.perf_counter() - t0
+    M.advect_scalar2D(mine["f"], mine["u"], mine["w"], mine["rho"], mine["rhow"], mine["flux"], mine["adz"])
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    M.gather_outputs({"f": mine["f"], "flux": mine["flux"]}, full, ns, dst=0)
+    torch.cuda.synchronize(); dist.barrier()
+    t_ga = time.perf_counter() - t0
+    per_in = sum(8 * n_loc * (full[k].numel() // ns if rank == 0 else 0) for k in names) if rank == 0 else 0
+    per_out = sum(8 * n_loc * (full[k].numel() // ns) for k in ("f", "flux")) if rank == 0 else 0
+    return {"ncrms_global": ns, "scatter_s": t_sc, "gather_s": t_ga,
+            "bytes_per_peer_scatter": per_in, "bytes_per_peer_gather": per_out,
+            "scatter_GBs_per_link": per_in / t_sc / 1e9, "gather_GBs_per_link": per_out / t_ga / 1e9,
+            "note": "root -> N-1 peers in one grouped send/recv; includes the pack / unpack kernels"}
 
 
 if __name__ == "__main__":

@@ -9,13 +9,13 @@ in fortran/; this Python face exists for bench.py, the tests and
 torch.distributed plumbing.  There is no CPU fallback here: if the HIP library
 is missing or no device is usable, calls raise.
 """
-from .capi import (MpdataError, Plan, VARIANT_EXACT, VARIANT_FAST, advect_scalar2D,
+from .capi import (LAYOUT_REFERENCE, LAYOUT_WAVEMAJOR, MpdataError, Plan, VARIANT_EXACT, VARIANT_FAST, advect_scalar2D,
                    advect_scalar2D_host, algorithmic_bytes, build_library, debug_stages, device_count,
-                   empty_staggered, fill_synthetic, get_variant, lib, lib_path, pack_shard, set_tile,
-                   set_variant, shapes, stage_shapes, unpack_shard)
+                   empty_staggered, fill_synthetic, get_variant, host_shapes, lib, lib_path, pack_shard,
+                   set_plan_layout, set_tile, set_variant, shapes, stage_shapes, unpack_shard)
 from .shard import gather_outputs, partition, scatter_inputs
 
-__all__ = ["MpdataError", "Plan", "VARIANT_EXACT", "VARIANT_FAST", "advect_scalar2D",
+__all__ = ["LAYOUT_REFERENCE", "LAYOUT_WAVEMAJOR", "host_shapes", "set_plan_layout", "MpdataError", "Plan", "VARIANT_EXACT", "VARIANT_FAST", "advect_scalar2D",
            "advect_scalar2D_host", "algorithmic_bytes", "build_library", "debug_stages", "device_count",
            "empty_staggered", "fill_synthetic", "get_variant", "lib", "lib_path", "pack_shard", "set_tile",
            "set_variant", "shapes", "stage_shapes", "unpack_shard", "partition", "scatter_inputs",

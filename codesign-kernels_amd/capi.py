@@ -21,6 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # MPDATA_HIP_LIB: load an alternative build of the library (kernel experiments)
 _LIB_PATH = os.environ.get("MPDATA_HIP_LIB") or os.path.join(HERE, "libmpdata_hip.so")
 VARIANT_EXACT, VARIANT_FAST = 0, 1
+LAYOUT_REFERENCE, LAYOUT_WAVEMAJOR = 0, 1
 
 _lib = None
 
@@ -70,6 +71,19 @@ def lib():
         L.mpdata_plan_download.argtypes = [vp, dp, dp]
         L.mpdata_plan_last_kernel_ms.restype = ci
         L.mpdata_plan_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        L.mpdata_plan_run_tracers.restype = ci
+        L.mpdata_plan_run_tracers.argtypes = [vp, ci, ci]
+        L.mpdata_plan_import_device.restype = ci
+        L.mpdata_plan_import_device.argtypes = [vp] + [vp] * 7 + [ci, ci]
+        L.mpdata_plan_export_device.restype = ci
+        L.mpdata_plan_export_device.argtypes = [vp, vp, vp, ci, ci]
+        L.mpdata_plan_set_stream.restype = ci
+        L.mpdata_plan_set_stream.argtypes = [vp, vp]
+        for name in ("mpdata_plan_layout", "mpdata_plan_device"):
+            getattr(L, name).restype = ci
+            getattr(L, name).argtypes = [vp]
+        L.mpdata_set_plan_layout.restype = ci
+        L.mpdata_set_plan_layout.argtypes = [ci]
         L.mpdata_fill_synthetic_device.restype = ci
         L.mpdata_fill_synthetic_device.argtypes = [dp, ci, i64, i64, i64, i64, ctypes.c_uint64, ci, vp]
         L.mpdata_pack_shard_device.restype = ci
@@ -123,6 +137,11 @@ def get_variant():
 
 def set_tile(t):
     return lib().mpdata_set_tile(int(t))
+
+
+def set_plan_layout(layout):
+    """Default device layout of new plans (LAYOUT_*); returns the previous one."""
+    return lib().mpdata_set_plan_layout(int(layout))
 
 
 def device_count():
@@ -247,6 +266,34 @@ def _host_dims(f):
     return ncrms, nxp6 - 6, nzm + 1, nt
 
 
+def host_shapes(ncrms, nx, nz, ntracers=1):
+    """numpy-side (Fortran order, the reference's declarations :479-484, :30) shapes."""
+    nzm = nz - 1
+    t = (ntracers,) if ntracers > 1 else ()
+    return {"adz": (ncrms, nzm), "f": (ncrms, nx + 6, nzm) + t, "u": (ncrms, nx + 5, nzm),
+            "w": (ncrms, nx + 4, nz), "rho": (ncrms, nzm), "rhow": (ncrms, nz),
+            "flux": (ncrms, nz) + t}
+
+
+def _host_ptrs(arrs, dims, dt, writable=()):
+    """Pointers of host arrays after checking dtype, order AND shape against what the C side
+    will copy (a wrongly shaped array would be an out-of-bounds hipMemcpy)."""
+    sh = host_shapes(*dims)
+    out = []
+    for name, a in arrs:
+        if a is None:
+            out.append(None)
+            continue
+        p = _host_ptr(a, name, name in writable, dt)
+        # a singleton axis (the reference's j = 1) and a trailing tracer axis of 1 are accepted
+        got = tuple(x for x in a.shape if x != 1)
+        want = tuple(x for x in sh[name] if x != 1)
+        if got != want:
+            raise MpdataError(-1, f"{name}: shape {tuple(a.shape)} != expected {sh[name]}")
+        out.append(p)
+    return out
+
+
 def advect_scalar2D_host(f, u, w, rho, rhow, flux, adz):
     """The drop-in, synchronous call on HOST arrays (numpy, Fortran order,
     reference shapes): H2D + kernel + D2H, like the reference's OpenACC
@@ -254,16 +301,16 @@ def advect_scalar2D_host(f, u, w, rho, rhow, flux, adz):
     ncrms, nx, nz, nt = _host_dims(f)
     dt = np.float32 if isinstance(f, np.ndarray) and f.dtype == np.float32 else np.float64
     fn = lib().mpdata_advect_scalar2d if dt == np.float64 else lib().mpdata_advect_scalar2d_f32
-    _check(fn(
-        ncrms, nx, nz, nt, _host_ptr(f, "f", True, dt), _host_ptr(u, "u", False, dt),
-        _host_ptr(w, "w", False, dt), _host_ptr(rho, "rho", False, dt),
-        _host_ptr(rhow, "rhow", False, dt), _host_ptr(adz, "adz", False, dt),
-        _host_ptr(flux, "flux", True, dt)))
+    ptrs = _host_ptrs((("f", f), ("u", u), ("w", w), ("rho", rho), ("rhow", rhow), ("adz", adz), ("flux", flux)),
+                      (ncrms, nx, nz, nt), dt, writable=("f", "flux"))
+    _check(fn(ncrms, nx, nz, nt, *ptrs))
 
 
 class Plan:
-    """Library-owned device buffers + stream (reference: `!$acc enter data`,
-    `update device`, `wait`, `update host`; :105-110, :237-242)."""
+    """Library-owned device state + stream (reference: `!$acc enter data`,
+    `update device`, `wait`, `update host`; :105-110, :237-242).  Arrays cross
+    the boundary in the reference layout; the plan keeps them in its own layout
+    (`layout`: LAYOUT_WAVEMAJOR for fp64 with nz <= 64, include/mpdata_hip.h 3)."""
 
     def __init__(self, ncrms, nx, nz, ntracers=1, dtype=np.float64):
         self._p = ctypes.c_void_p()
@@ -271,24 +318,69 @@ class Plan:
         if self._dt not in (np.float64, np.float32):
             raise MpdataError(-1, f"Plan: dtype {dtype} is neither float64 nor float32")
         self._sfx = "" if self._dt == np.float64 else "_f32"
+        self.dims = (int(ncrms), int(nx), int(nz), int(ntracers))
         _check(getattr(lib(), "mpdata_plan_create" + self._sfx)(ncrms, nx, nz, ntracers, ctypes.byref(self._p)))
 
-    def upload(self, f, u, w, rho, rhow, adz, flux=None):
-        dt = self._dt
-        fl = _host_ptr(flux, "flux", False, dt) if flux is not None else None
-        _check(getattr(lib(), "mpdata_plan_upload" + self._sfx)(
-            self._p, _host_ptr(f, "f", False, dt), _host_ptr(u, "u", False, dt), _host_ptr(w, "w", False, dt),
-            _host_ptr(rho, "rho", False, dt), _host_ptr(rhow, "rhow", False, dt), _host_ptr(adz, "adz", False, dt), fl))
+    @property
+    def layout(self):
+        return lib().mpdata_plan_layout(self._p)
 
-    def run(self):
-        _check(lib().mpdata_plan_run(self._p))
+    @property
+    def device(self):
+        return lib().mpdata_plan_device(self._p)
+
+    def upload(self, f, u, w, rho, rhow, adz, flux=None):
+        ptrs = _host_ptrs((("f", f), ("u", u), ("w", w), ("rho", rho), ("rhow", rhow), ("adz", adz), ("flux", flux)),
+                          self.dims, self._dt)
+        _check(getattr(lib(), "mpdata_plan_upload" + self._sfx)(self._p, *ptrs))
+
+    def run(self, first_tracer=None, ntracers=None):
+        if first_tracer is None:
+            _check(lib().mpdata_plan_run(self._p))
+        else:
+            _check(lib().mpdata_plan_run_tracers(self._p, int(first_tracer), int(1 if ntracers is None else ntracers)))
 
     def sync(self):
         _check(lib().mpdata_plan_sync(self._p))
 
     def download(self, f, flux):
-        _check(getattr(lib(), "mpdata_plan_download" + self._sfx)(
-            self._p, _host_ptr(f, "f", True, self._dt), _host_ptr(flux, "flux", True, self._dt)))
+        ptrs = _host_ptrs((("f", f), ("flux", flux)), self.dims, self._dt, writable=("f", "flux"))
+        _check(getattr(lib(), "mpdata_plan_download" + self._sfx)(self._p, *ptrs))
+
+    def _tdt(self):
+        import torch
+        return torch.float64 if self._dt == np.float64 else torch.float32
+
+    def import_device(self, f=None, u=None, w=None, rho=None, rhow=None, adz=None, flux=None, first_tracer=0):
+        """Reference-layout DEVICE tensors (reversed-axes torch layout) -> the plan, on the plan's
+        stream.  None = keep what the plan has.  f / flux: ([ntr,] nzm, nx+6, ncrms) /
+        ([ntr,] nz, ncrms) covering tracers first_tracer .. first_tracer+ntr-1."""
+        ncrms, nx, nz, nt = self.dims
+        ntr = 1
+        for t in (f, flux):
+            if t is not None and t.dim() == (4 if t is f else 3):
+                ntr = t.shape[0]
+        sh = shapes(ncrms, nx, nz, ntr)
+        args = []
+        for name, t in (("f", f), ("u", u), ("w", w), ("rho", rho), ("rhow", rhow), ("adz", adz), ("flux", flux)):
+            args.append(None if t is None else _dev_ptr(t, sh[name], name, self._tdt()))
+        _check(lib().mpdata_plan_import_device(self._p, *args, int(first_tracer), int(ntr)))
+
+    def export_device(self, f=None, flux=None, first_tracer=0):
+        """The plan's f / flux of tracers first_tracer.. -> reference-layout device tensors."""
+        ncrms, nx, nz, nt = self.dims
+        ntr = 1
+        for t in (f, flux):
+            if t is not None and t.dim() == (4 if t is f else 3):
+                ntr = t.shape[0]
+        sh = shapes(ncrms, nx, nz, ntr)
+        pf = None if f is None else _dev_ptr(f, sh["f"], "f", self._tdt())
+        pl = None if flux is None else _dev_ptr(flux, sh["flux"], "flux", self._tdt())
+        _check(lib().mpdata_plan_export_device(self._p, pf, pl, int(first_tracer), int(ntr)))
+
+    def set_stream(self, stream=None):
+        """Run on a torch stream (default: torch's current stream) from now on."""
+        _check(lib().mpdata_plan_set_stream(self._p, _stream_handle(stream)))
 
     def last_kernel_ms(self):
         ms = ctypes.c_double()
@@ -321,13 +413,36 @@ def fill_synthetic(t, name, seed, dist, ncrms_global=None, sl0=0, stream=None):
               _stream_handle(stream)))
 
 
-def pack_shard(full, sl0, nloc, out=None, stream=None):
-    """Contiguous copy of CRM instances [sl0, sl0+nloc) of a device tensor."""
+def _shard_check(t, name):
     import torch
-    ncrms = full.shape[-1]
-    rows = full.numel() // ncrms
+    if not (t.is_cuda and t.is_contiguous() and t.dtype in (torch.float64, torch.float32)):
+        raise MpdataError(-1, f"{name}: need a contiguous float64 or float32 device tensor")
+
+
+def _shard_dims(full, shard):
+    """rows, ncrms, nloc IN UNITS OF 8 BYTES for the fp64 pack kernel: an fp32 tensor is moved as
+    pairs of elements, which needs even ncrms, nloc and sl0."""
+    _shard_check(full, "full")
+    _shard_check(shard, "shard")
+    if full.dtype != shard.dtype or tuple(full.shape[:-1]) != tuple(shard.shape[:-1]):
+        raise MpdataError(-1, f"shard {tuple(shard.shape)} {shard.dtype} does not match full "
+                              f"{tuple(full.shape)} {full.dtype}")
+    return full.numel() // full.shape[-1], full.shape[-1], shard.shape[-1]
+
+
+def pack_shard(full, sl0, nloc, out=None, stream=None):
+    """Contiguous copy of CRM instances [sl0, sl0+nloc) of a device tensor (float64, or
+    float32 with even ncrms, nloc, sl0)."""
+    import torch
     if out is None:
         out = torch.empty(full.shape[:-1] + (nloc,), dtype=full.dtype, device=full.device)
+    rows, ncrms, nl = _shard_dims(full, out)
+    if nl != nloc:
+        raise MpdataError(-1, f"out holds {nl} instances, asked for {nloc}")
+    if full.dtype == torch.float32:
+        if (ncrms | nloc | sl0) & 1:
+            raise MpdataError(-1, "float32 shards need even ncrms, nloc and sl0")
+        ncrms, nloc, sl0 = ncrms // 2, nloc // 2, sl0 // 2
     _check(lib().mpdata_pack_shard_device(ctypes.c_void_p(full.data_ptr()),
                                           ctypes.c_void_p(out.data_ptr()), rows, ncrms, sl0, nloc,
                                           _stream_handle(stream)))
@@ -335,8 +450,12 @@ def pack_shard(full, sl0, nloc, out=None, stream=None):
 
 
 def unpack_shard(full, shard, sl0, stream=None):
-    ncrms, nloc = full.shape[-1], shard.shape[-1]
-    rows = full.numel() // ncrms
+    import torch
+    rows, ncrms, nloc = _shard_dims(full, shard)
+    if full.dtype == torch.float32:
+        if (ncrms | nloc | sl0) & 1:
+            raise MpdataError(-1, "float32 shards need even ncrms, nloc and sl0")
+        ncrms, nloc, sl0 = ncrms // 2, nloc // 2, sl0 // 2
     _check(lib().mpdata_unpack_shard_device(ctypes.c_void_p(full.data_ptr()),
                                             ctypes.c_void_p(shard.data_ptr()), rows, ncrms, sl0,
                                             nloc, _stream_handle(stream)))

@@ -25,6 +25,26 @@ struct MpdataArgsT {
 typedef MpdataArgsT<double> MpdataArgs;
 typedef MpdataArgsT<float> MpdataArgsF32;
 
+// Wave-major kernels (mpdata_kernel_wm_body.h): arrays in the plan-private layout
+//   f,u,w [tracer][tile][column 0..nx+5][instance-in-tile][level 0..nzm-1],
+//   kc    [tile][3 = rho,adz,rhow][instance-in-tile][level],   flux [tracer][tile][inst][level]
+template <typename R>
+struct MpdataWmArgsT {
+  R* f;
+  const R* u;
+  const R* w;
+  const R* kc;
+  R* flux;
+  int ntiles;              // ceil(ncrms / instances per tile)
+  int nx, nz;
+  int ntracers;            // tracers this launch works on (f, flux point at the first of them)
+  long long tile_elems;    // elements between consecutive tiles of f, u, w: (nx+6) * SLP * nzm
+  long long f_tstride;     // elements between consecutive tracers of f: ntiles * tile_elems
+  long long flux_tstride;  // ... of flux: ntiles * SLP * nzm
+  int reverse;             // walk the tiles from the last to the first
+};
+typedef MpdataWmArgsT<double> MpdataWmArgs;
+
 // One tiling of the kernel template (W columns per thread, SPW strips per
 // wave, NWV waves per workgroup).
 struct MpdataTileInfo {

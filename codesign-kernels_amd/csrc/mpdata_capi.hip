@@ -14,6 +14,7 @@
 
 #include "mpdata_args.h"
 #include "mpdata_hip.h"
+#include "mpdata_layout.h"
 
 namespace mpdata_exact {
 int max_tile_id();
@@ -263,18 +264,6 @@ int fill_device(R* a, int sid, int64_t rows, int64_t ncrms_global, int64_t sl0, 
 
 }  // namespace
 
-struct mpdata_plan {
-  int64_t ncrms;
-  int nx, nz, ntracers;
-  int eb;  // bytes per real: 8 (fp64 plan) or 4 (fp32 plan)
-  Sizes sz;
-  Arena arena;
-  void *f, *u, *w, *rho, *rhow, *adz, *flux;  // = arena.p[0..6]
-  hipStream_t stream;
-  hipEvent_t ev0, ev1;
-  bool uploaded, ran;
-};
-
 extern "C" {
 
 int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers, double* f,
@@ -291,26 +280,251 @@ int mpdata_advect_scalar2d_f32_device(int64_t ncrms, int nx, int nz, int ntracer
   return advect_device<float>(ncrms, nx, nz, ntracers, f, u, w, rho, rhow, adz, flux, stream);
 }
 
+}  // extern "C"
+
+// ---- plans ---------------------------------------------------------------------------------
+// A plan owns the device state of one problem (what the OpenACC `enter data pcreate` of the
+// reference does, :105, :280, :662) on the device that was current when it was created; every
+// plan call switches to that device and back.  Variant and layout are fixed at creation.
+// fp64 plans with nz <= 64 keep the arrays in the wave-major layout of
+// mpdata_kernel_wm_body.h and convert in upload / download / import / export; other plans
+// (fp32; nz > 64) keep the reference layout and run the x-/k-marching kernels.
+namespace mpdata_exact { bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream); }
+namespace mpdata_fast { bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream); }
+
+namespace {
+int g_layout = -1;  // -1: read MPDATA_PLAN_LAYOUT on first use
+int plan_layout_default() {
+  if (g_layout < 0) {
+    const char* v = getenv("MPDATA_PLAN_LAYOUT");
+    g_layout = (v && (!strcmp(v, "reference") || !strcmp(v, "0"))) ? MPDATA_LAYOUT_REFERENCE : MPDATA_LAYOUT_WAVEMAJOR;
+  }
+  return g_layout;
+}
+int serpentine() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MPDATA_SERPENTINE");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v;
+}
+int wm_wpb() { return 4; }  // waves (tiles) per workgroup of the wave-major kernels
+struct DevGuard {
+  int prev = -1, dev;
+  explicit DevGuard(int d) : dev(d) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DevGuard() {
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+  }
+};
+}  // namespace
+
+struct mpdata_plan {
+  int64_t ncrms;
+  int nx, nz, ntracers;
+  int eb;        // bytes per real: 8 (fp64 plan) or 4 (fp32 plan)
+  int device;    // the plan's device
+  int variant;   // MPDATA_VARIANT_* at creation
+  int layout;    // MPDATA_LAYOUT_*
+  Sizes sz;      // element counts of the reference-layout arrays
+  // reference-layout plans
+  Arena arena;
+  void *f, *u, *w, *rho, *rhow, *adz, *flux;  // = arena.p[0..6]
+  // wave-major plans
+  int lps, slp, wpb, ntiles;
+  long long chunk, tile_elems;
+  void *pf, *pu, *pw, *pkc, *pflux;  // private arrays
+  void* stage;                       // reference-layout staging: one tracer of f (or u, w)
+  size_t stage_elems;
+  void* flux_ref;                    // flux in the reference layout (level nz is carried through)
+  hipStream_t stream;
+  bool own_stream;
+  hipEvent_t ev0, ev1;
+  bool uploaded, ran;
+  unsigned runs;   // launches so far (serpentine tile order)
+};
+
+namespace {
+
+// conversion jobs of a wave-major plan: which = 0 f, 1 u, 2 w, 3 rho, 4 rhow, 5 adz, 6 flux
+MpdataLayoutJob wm_job(const mpdata_plan* p, int which, void* ref, int first_tracer, int ntr) {
+  MpdataLayoutJob j;
+  const int nzm = p->nz - 1, nx = p->nx;
+  j.ref = ref; j.ncrms = p->ncrms; j.nlev = nzm; j.ntr = 1; j.slp = p->slp; j.ntiles = p->ntiles;
+  j.chunk = p->chunk; j.ref_tstride = 0; j.prv_tstride = 0; j.prv_col0 = 0;
+  j.ref_colmul = 1;
+  switch (which) {
+    case 0:
+      j.prv = (double*)p->pf + (long long)first_tracer * p->ntiles * p->tile_elems;
+      j.ncols = nx + 6; j.ref_levmul = nx + 6; j.prv_tile_stride = p->tile_elems;
+      j.ntr = ntr; j.ref_tstride = (long long)p->ncrms * (nx + 6) * nzm; j.prv_tstride = (long long)p->ntiles * p->tile_elems;
+      break;
+    case 1: j.prv = p->pu; j.ncols = nx + 5; j.ref_levmul = nx + 5; j.prv_col0 = 1; j.prv_tile_stride = p->tile_elems; break;
+    case 2: j.prv = p->pw; j.ncols = nx + 4; j.ref_levmul = nx + 4; j.prv_col0 = 1; j.prv_tile_stride = p->tile_elems; break;
+    case 3: case 4: case 5:   // kc = [tile][rho, adz, rhow][chunk]
+      j.prv = p->pkc; j.ncols = 1; j.ref_colmul = 0; j.ref_levmul = 1; j.prv_tile_stride = 3 * p->chunk;
+      j.prv_col0 = which == 3 ? 0 : (which == 5 ? 1 : 2);
+      break;
+    default:
+      j.prv = (double*)p->pflux + (long long)first_tracer * p->ntiles * p->chunk;
+      j.ncols = 1; j.ref_colmul = 0; j.ref_levmul = 1; j.prv_tile_stride = p->chunk;
+      j.ntr = ntr; j.ref_tstride = (long long)p->ncrms * p->nz; j.prv_tstride = (long long)p->ntiles * p->chunk;
+      break;
+  }
+  return j;
+}
+
+int wm_lps_for(int nz) { return nz <= 8 ? 8 : nz <= 16 ? 16 : nz <= 32 ? 32 : nz <= 64 ? 64 : 0; }
+
+int plan_check(const mpdata_plan* p, int eb) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (p->eb != eb) return set_err(MPDATA_ESTATE, "plan precision (%d-byte reals) does not match the call", p->eb);
+  return 0;
+}
+int tracer_range(const mpdata_plan* p, int first, int count) {
+  if (first < 0 || count < 1 || first + count > p->ntracers)
+    return set_err(MPDATA_EINVAL, "tracer range [%d, %d) outside the plan's %d tracers", first, first + count, p->ntracers);
+  return 0;
+}
+
+// Arrays in the reference layout -> the plan.  `dev` says where the pointers live.  Null
+// pointers are skipped (the plan keeps what it has).  f / flux cover `count` tracers.
+int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, const void* rho,
+                const void* rhow, const void* adz, const void* flux, int first, int count, bool dev) {
+  const int eb = p->eb;
+  const size_t f1 = p->sz.f / p->ntracers;  // elements of one tracer of f
+  const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (p->layout == MPDATA_LAYOUT_REFERENCE) {
+    if (f) HIP_TRY(hipMemcpyAsync((char*)p->f + first * f1 * eb, f, f1 * count * eb, kind, p->stream));
+    if (u) HIP_TRY(hipMemcpyAsync(p->u, u, p->sz.u * eb, kind, p->stream));
+    if (w) HIP_TRY(hipMemcpyAsync(p->w, w, p->sz.w * eb, kind, p->stream));
+    if (rho) HIP_TRY(hipMemcpyAsync(p->rho, rho, p->sz.k * eb, kind, p->stream));
+    if (rhow) HIP_TRY(hipMemcpyAsync(p->rhow, rhow, p->sz.kz * eb, kind, p->stream));
+    if (adz) HIP_TRY(hipMemcpyAsync(p->adz, adz, p->sz.k * eb, kind, p->stream));
+    if (flux) HIP_TRY(hipMemcpyAsync((char*)p->flux + first * p->sz.kz * eb, flux, p->sz.kz * count * eb, kind, p->stream));
+    return 0;
+  }
+  // wave-major: device sources are converted in place, host sources go through the staging
+  // buffer one array (one tracer of f) at a time
+  auto one = [&](int which, const void* src, size_t elems, int tr) -> int {
+    void* ref = const_cast<void*>(src);
+    if (!dev) {
+      HIP_TRY(hipMemcpyAsync(p->stage, src, elems * eb, hipMemcpyHostToDevice, p->stream));
+      ref = p->stage;
+    }
+    HIP_TRY(mpdata_layout_convert(wm_job(p, which, ref, tr, 1), eb, true, p->stream));
+    return 0;
+  };
+  int rc = 0;
+  if (f) {
+    if (dev) {
+      HIP_TRY(mpdata_layout_convert(wm_job(p, 0, const_cast<void*>(f), first, count), eb, true, p->stream));
+    } else {
+      for (int t = 0; t < count && !rc; ++t) rc = one(0, (const char*)f + (size_t)t * f1 * eb, f1, first + t);
+    }
+  }
+  if (!rc && u) rc = one(1, u, p->sz.u, 0);
+  if (!rc && w) rc = one(2, w, p->sz.w, 0);
+  if (!rc && rho) rc = one(3, rho, p->sz.k, 0);
+  if (!rc && rhow) rc = one(4, rhow, p->sz.kz, 0);
+  if (!rc && adz) rc = one(5, adz, p->sz.k, 0);
+  if (!rc && flux) {
+    // kept twice: in the reference layout (level nz is carried through to the export) and in the
+    // private array (a tracer that is never run exports what was imported)
+    void* fr = (char*)p->flux_ref + (size_t)first * p->sz.kz * eb;
+    HIP_TRY(hipMemcpyAsync(fr, flux, p->sz.kz * count * eb, kind, p->stream));
+    HIP_TRY(mpdata_layout_convert(wm_job(p, 6, fr, first, count), eb, true, p->stream));
+  }
+  return rc;
+}
+
+int plan_export(mpdata_plan* p, void* f, void* flux, int first, int count, bool dev) {
+  const int eb = p->eb;
+  const size_t f1 = p->sz.f / p->ntracers;
+  const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (p->layout == MPDATA_LAYOUT_REFERENCE) {
+    if (f) HIP_TRY(hipMemcpyAsync(f, (char*)p->f + first * f1 * eb, f1 * count * eb, kind, p->stream));
+    if (flux) HIP_TRY(hipMemcpyAsync(flux, (char*)p->flux + first * p->sz.kz * eb, p->sz.kz * count * eb, kind, p->stream));
+    return 0;
+  }
+  if (f) {
+    if (dev) {
+      HIP_TRY(mpdata_layout_convert(wm_job(p, 0, f, first, count), eb, false, p->stream));
+    } else {
+      for (int t = 0; t < count; ++t) {
+        HIP_TRY(mpdata_layout_convert(wm_job(p, 0, p->stage, first + t, 1), eb, false, p->stream));
+        HIP_TRY(hipMemcpyAsync((char*)f + (size_t)t * f1 * eb, p->stage, f1 * eb, hipMemcpyDeviceToHost, p->stream));
+      }
+    }
+  }
+  if (flux) {
+    // levels 1..nzm from the kernel's result; level nz is whatever was uploaded (the reference
+    // never writes it, :541, :624)
+    void* fr = (char*)p->flux_ref + (size_t)first * p->sz.kz * eb;
+    HIP_TRY(mpdata_layout_convert(wm_job(p, 6, fr, first, count), eb, false, p->stream));
+    HIP_TRY(hipMemcpyAsync(flux, fr, p->sz.kz * count * eb, kind, p->stream));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
 static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan, int eb) {
   if (!plan) return set_err(MPDATA_EINVAL, "null plan pointer");
   *plan = nullptr;
   int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
+  const int var = variant();
+  const bool wmaj = eb == 8 && wm_lps_for(nz) != 0 && plan_layout_default() == MPDATA_LAYOUT_WAVEMAJOR &&
+                    tile_override() < 0;
   MpdataTileInfo t;
-  rc = choose_tile(variant(), ncrms, nx, nz, &t, eb);
-  if (rc) return rc;
+  if (!wmaj) {
+    rc = choose_tile(var, ncrms, nx, nz, &t, eb);
+    if (rc) return rc;
+  }
   mpdata_plan* p = (mpdata_plan*)calloc(1, sizeof(mpdata_plan));
   if (!p) return set_err(MPDATA_EINVAL, "out of host memory");
   p->ncrms = ncrms; p->nx = nx; p->nz = nz; p->ntracers = ntracers; p->eb = eb;
+  p->variant = var;
+  p->layout = wmaj ? MPDATA_LAYOUT_WAVEMAJOR : MPDATA_LAYOUT_REFERENCE;
   p->sz = sizes_of(ncrms, nx, nz, ntracers);
-  const size_t nb[7] = {p->sz.f * eb, p->sz.u * eb, p->sz.w * eb, p->sz.k * eb, p->sz.kz * eb, p->sz.k * eb,
-                        p->sz.kz * ntracers * eb};
-  hipError_t e = arena_alloc(p->arena, nb);
-  if (e == hipSuccess) {
-    p->f = p->arena.p[0]; p->u = p->arena.p[1]; p->w = p->arena.p[2]; p->rho = p->arena.p[3];
-    p->rhow = p->arena.p[4]; p->adz = p->arena.p[5]; p->flux = p->arena.p[6];
+  hipError_t e = hipGetDevice(&p->device);
+  if (e == hipSuccess && !wmaj) {
+    const size_t nb[7] = {p->sz.f * eb, p->sz.u * eb, p->sz.w * eb, p->sz.k * eb, p->sz.kz * eb, p->sz.k * eb,
+                          p->sz.kz * ntracers * eb};
+    e = arena_alloc(p->arena, nb);
+    if (e == hipSuccess) {
+      p->f = p->arena.p[0]; p->u = p->arena.p[1]; p->w = p->arena.p[2]; p->rho = p->arena.p[3];
+      p->rhow = p->arena.p[4]; p->adz = p->arena.p[5]; p->flux = p->arena.p[6];
+    }
+  }
+  if (e == hipSuccess && wmaj) {
+    const int nzm = nz - 1;
+    p->lps = wm_lps_for(nz); p->slp = 64 / p->lps; p->wpb = wm_wpb();
+    p->ntiles = (int)((ncrms + p->slp - 1) / p->slp);
+    p->chunk = (long long)p->slp * nzm;
+    p->tile_elems = (long long)(nx + 6) * p->chunk;
+    const size_t tile_arr = (size_t)p->ntiles * p->tile_elems * eb;
+    const size_t f1 = p->sz.f / ntracers;
+    p->stage_elems = f1 > p->sz.w ? f1 : p->sz.w;
+    if (e == hipSuccess) e = hipMalloc(&p->pf, tile_arr * ntracers);
+    if (e == hipSuccess) e = hipMalloc(&p->pu, tile_arr);
+    if (e == hipSuccess) e = hipMalloc(&p->pw, tile_arr);
+    if (e == hipSuccess) e = hipMalloc(&p->pkc, (size_t)p->ntiles * 3 * p->chunk * eb);
+    if (e == hipSuccess) e = hipMalloc(&p->pflux, (size_t)p->ntiles * p->chunk * ntracers * eb);
+    if (e == hipSuccess) e = hipMalloc(&p->stage, p->stage_elems * eb);
+    if (e == hipSuccess) e = hipMalloc(&p->flux_ref, p->sz.kz * ntracers * eb);
+    // u, w have column slots that nothing ever fills or fetches (c = 0; c = nx+5 of w)
+    if (e == hipSuccess) e = hipMemset(p->pu, 0, tile_arr);
+    if (e == hipSuccess) e = hipMemset(p->pw, 0, tile_arr);
   }
   if (e == hipSuccess) e = hipStreamCreate(&p->stream);
+  if (e == hipSuccess) p->own_stream = true;
   if (e == hipSuccess) e = hipEventCreate(&p->ev0);
   if (e == hipSuccess) e = hipEventCreate(&p->ev1);
   if (e != hipSuccess) {
@@ -329,21 +543,20 @@ int mpdata_plan_create_f32(int64_t ncrms, int nx, int nz, int ntracers, mpdata_p
 
 static int plan_upload(mpdata_plan* p, const void* f, const void* u, const void* w, const void* rho,
                        const void* rhow, const void* adz, const void* flux, int eb) {
-  if (!p) return set_err(MPDATA_EINVAL, "null plan");
-  if (p->eb != eb) return set_err(MPDATA_ESTATE, "plan precision (%d-byte reals) does not match the call", p->eb);
+  int rc = plan_check(p, eb);
+  if (rc) return rc;
   if (!f || !u || !w || !rho || !rhow || !adz) return set_err(MPDATA_EINVAL, "null array pointer");
-  HIP_TRY(hipMemcpyAsync(p->f, f, p->sz.f * eb, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->u, u, p->sz.u * eb, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->w, w, p->sz.w * eb, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->rho, rho, p->sz.k * eb, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->rhow, rhow, p->sz.kz * eb, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->adz, adz, p->sz.k * eb, hipMemcpyHostToDevice, p->stream));
+  DevGuard g(p->device);
   // flux is intent(out) in the reference but its level nz is never written
   // (reference :541, :624 touch 1..nzm only): carry the caller's values over
-  if (flux)
-    HIP_TRY(hipMemcpyAsync(p->flux, flux, p->sz.kz * p->ntracers * eb, hipMemcpyHostToDevice, p->stream));
-  else
-    HIP_TRY(hipMemsetAsync(p->flux, 0, p->sz.kz * p->ntracers * eb, p->stream));
+  void* fl = p->layout == MPDATA_LAYOUT_REFERENCE ? p->flux : p->flux_ref;
+  if (!flux) {
+    HIP_TRY(hipMemsetAsync(fl, 0, p->sz.kz * p->ntracers * eb, p->stream));
+    if (p->layout == MPDATA_LAYOUT_WAVEMAJOR)
+      HIP_TRY(hipMemsetAsync(p->pflux, 0, (size_t)p->ntiles * p->chunk * p->ntracers * eb, p->stream));
+  }
+  rc = plan_import(p, f, u, w, rho, rhow, adz, flux, 0, p->ntracers, false);
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(p->stream));
   p->uploaded = true;
   return 0;
@@ -359,38 +572,87 @@ int mpdata_plan_upload_f32(mpdata_plan* p, const float* f, const float* u, const
   return plan_upload(p, f, u, w, rho, rhow, adz, flux, 4);
 }
 
-int mpdata_plan_run(mpdata_plan* p) {
+int mpdata_plan_import_device(mpdata_plan* p, const void* f, const void* u, const void* w, const void* rho,
+                              const void* rhow, const void* adz, const void* flux, int first_tracer,
+                              int ntracers) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  int rc = tracer_range(p, first_tracer, ntracers);
+  if (rc) return rc;
+  DevGuard g(p->device);
+  rc = plan_import(p, f, u, w, rho, rhow, adz, flux, first_tracer, ntracers, true);
+  if (rc) return rc;
+  p->uploaded = true;  // (the caller is responsible for having provided every array once)
+  return 0;
+}
+
+int mpdata_plan_export_device(mpdata_plan* p, void* f, void* flux, int first_tracer, int ntracers) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  int rc = tracer_range(p, first_tracer, ntracers);
+  if (rc) return rc;
+  if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_export_device before upload / import");
+  DevGuard g(p->device);
+  return plan_export(p, f, flux, first_tracer, ntracers, true);
+}
+
+int mpdata_plan_run_tracers(mpdata_plan* p, int first, int count) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run before mpdata_plan_upload");
-  HIP_TRY(hipEventRecord(p->ev0, p->stream));
-  int rc;
-  if (p->eb == 8)
-    rc = mpdata_advect_scalar2d_device(p->ncrms, p->nx, p->nz, p->ntracers, (double*)p->f, (const double*)p->u,
-                                       (const double*)p->w, (const double*)p->rho, (const double*)p->rhow,
-                                       (const double*)p->adz, (double*)p->flux, (void*)p->stream);
-  else
-    rc = mpdata_advect_scalar2d_f32_device(p->ncrms, p->nx, p->nz, p->ntracers, (float*)p->f, (const float*)p->u,
-                                           (const float*)p->w, (const float*)p->rho, (const float*)p->rhow,
-                                           (const float*)p->adz, (float*)p->flux, (void*)p->stream);
+  int rc = tracer_range(p, first, count);
   if (rc) return rc;
+  DevGuard g(p->device);
+  HIP_TRY(hipEventRecord(p->ev0, p->stream));
+  if (p->layout == MPDATA_LAYOUT_WAVEMAJOR) {
+    MpdataWmArgs a;
+    a.f = (double*)p->pf + (long long)first * p->ntiles * p->tile_elems;
+    a.u = (const double*)p->pu; a.w = (const double*)p->pw; a.kc = (const double*)p->pkc;
+    a.flux = (double*)p->pflux + (long long)first * p->ntiles * p->chunk;
+    a.ntiles = p->ntiles; a.nx = p->nx; a.nz = p->nz; a.ntracers = count;
+    a.tile_elems = p->tile_elems;
+    a.f_tstride = (long long)p->ntiles * p->tile_elems;
+    a.flux_tstride = (long long)p->ntiles * p->chunk;
+    a.reverse = serpentine() ? (int)(p->runs++ & 1u) : 0;
+    const bool ok = p->variant == MPDATA_VARIANT_FAST ? mpdata_fast::launch_wm(p->lps, p->wpb, a, (void*)p->stream)
+                                                      : mpdata_exact::launch_wm(p->lps, p->wpb, a, (void*)p->stream);
+    if (!ok) return set_err(MPDATA_EINVAL, "wave-major kernel LPS=%d WPB=%d not instantiated", p->lps, p->wpb);
+    HIP_TRY(hipGetLastError());
+  } else {
+    const size_t f1 = p->sz.f / p->ntracers;
+    const int var_prev = variant();
+    g_variant = p->variant;
+    if (p->eb == 8)
+      rc = mpdata_advect_scalar2d_device(p->ncrms, p->nx, p->nz, count, (double*)p->f + first * f1, (const double*)p->u,
+                                         (const double*)p->w, (const double*)p->rho, (const double*)p->rhow,
+                                         (const double*)p->adz, (double*)p->flux + first * p->sz.kz, (void*)p->stream);
+    else
+      rc = mpdata_advect_scalar2d_f32_device(p->ncrms, p->nx, p->nz, count, (float*)p->f + first * f1, (const float*)p->u,
+                                             (const float*)p->w, (const float*)p->rho, (const float*)p->rhow,
+                                             (const float*)p->adz, (float*)p->flux + first * p->sz.kz, (void*)p->stream);
+    g_variant = var_prev;
+    if (rc) return rc;
+  }
   HIP_TRY(hipEventRecord(p->ev1, p->stream));
   p->ran = true;
   return 0;
 }
+int mpdata_plan_run(mpdata_plan* p) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  return mpdata_plan_run_tracers(p, 0, p->ntracers);
+}
 
 int mpdata_plan_sync(mpdata_plan* p) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  DevGuard g(p->device);
   HIP_TRY(hipStreamSynchronize(p->stream));
   return 0;
 }
 
 static int plan_download(mpdata_plan* p, void* f, void* flux, int eb) {
-  if (!p) return set_err(MPDATA_EINVAL, "null plan");
-  if (p->eb != eb) return set_err(MPDATA_ESTATE, "plan precision (%d-byte reals) does not match the call", p->eb);
+  int rc = plan_check(p, eb);
+  if (rc) return rc;
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_download before upload");
-  if (f) HIP_TRY(hipMemcpyAsync(f, p->f, p->sz.f * eb, hipMemcpyDeviceToHost, p->stream));
-  if (flux)
-    HIP_TRY(hipMemcpyAsync(flux, p->flux, p->sz.kz * p->ntracers * eb, hipMemcpyDeviceToHost, p->stream));
+  DevGuard g(p->device);
+  rc = plan_export(p, f, flux, 0, p->ntracers, false);
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(p->stream));
   return 0;
 }
@@ -400,6 +662,7 @@ int mpdata_plan_download_f32(mpdata_plan* p, float* f, float* flux) { return pla
 int mpdata_plan_last_kernel_ms(mpdata_plan* p, double* ms) {
   if (!p || !ms) return set_err(MPDATA_EINVAL, "null argument");
   if (!p->ran) return set_err(MPDATA_ESTATE, "no run recorded");
+  DevGuard g(p->device);
   HIP_TRY(hipEventSynchronize(p->ev1));
   float t = 0.f;
   HIP_TRY(hipEventElapsedTime(&t, p->ev0, p->ev1));
@@ -407,12 +670,33 @@ int mpdata_plan_last_kernel_ms(mpdata_plan* p, double* ms) {
   return 0;
 }
 
+int mpdata_plan_set_stream(mpdata_plan* p, void* stream) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  DevGuard g(p->device);
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->own_stream) (void)hipStreamDestroy(p->stream);
+  p->stream = (hipStream_t)stream;
+  p->own_stream = false;
+  return 0;
+}
+int mpdata_plan_layout(const mpdata_plan* p) { return p ? p->layout : MPDATA_EINVAL; }
+int mpdata_plan_device(const mpdata_plan* p) { return p ? p->device : MPDATA_EINVAL; }
+int mpdata_set_plan_layout(int layout) {
+  const int prev = plan_layout_default();
+  if (layout == MPDATA_LAYOUT_REFERENCE || layout == MPDATA_LAYOUT_WAVEMAJOR) g_layout = layout;
+  return prev;
+}
+
 int mpdata_plan_destroy(mpdata_plan* p) {
   if (!p) return 0;
+  DevGuard g(p->device);
   arena_free(p->arena);
+  void* bufs[7] = {p->pf, p->pu, p->pw, p->pkc, p->pflux, p->stage, p->flux_ref};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
-  if (p->stream) (void)hipStreamDestroy(p->stream);
+  if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
   free(p);
   return 0;
 }

@@ -3,6 +3,7 @@
 // defining MPDATA_NS; exports <MPDATA_NS>::launch(tile, ...).
 #include "mpdata_kernel_body.h"
 #include "mpdata_kernel_v2_body.h"
+#include "mpdata_kernel_wm_body.h"
 
 namespace MPDATA_NS {
 
@@ -64,6 +65,35 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
     hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, true>), grid, block, 0, (hipStream_t)stream, b);
   else
     hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, false>), grid, block, 0, (hipStream_t)stream, b);
+}
+
+// wave-major kernels (mpdata_kernel_wm_body.h, the plan API): LPS = lanes per instance (>= nz),
+// WPB = waves per workgroup.  Returns false if (lps, wpb) is not instantiated.
+#define MPDATA_WM_LPS(X) X(8) X(16) X(32) X(64)
+template <int LPS, int WPB>
+static void launch_wm_t(const MpdataWmArgs& a, void* stream) {
+  // ntracers == 1: wave = tile in dispatch order; else the per-XCD tracer walk (see the kernel)
+  if (a.ntracers == 1) {
+    const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS, WPB, true>), dim3(blocks), dim3(64 * WPB), 0,
+                       (hipStream_t)stream, a);
+  } else {
+    const long long per_xcd = ((long long)(a.ntiles + 7) / 8) * a.ntracers;  // waves of one XCD
+    const unsigned blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS, WPB, false>), dim3(blocks), dim3(64 * WPB), 0,
+                       (hipStream_t)stream, a);
+  }
+}
+bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream) {
+  if (wpb != 4) return false;
+#define X(LPS_)                     \
+  if (lps == LPS_) {                \
+    launch_wm_t<LPS_, 4>(a, stream); \
+    return true;                    \
+  }
+  MPDATA_WM_LPS(X)
+#undef X
+  return false;
 }
 
 int max_tile_id() { return 43; }

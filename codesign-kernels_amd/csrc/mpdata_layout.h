@@ -1,0 +1,30 @@
+// mpdata_layout.h -- host interface of the layout-conversion kernels (mpdata_layout.hip).
+#ifndef MPDATA_LAYOUT_H
+#define MPDATA_LAYOUT_H
+#include <hip/hip_runtime.h>
+
+// One array (all tracers of it) between the two layouts.
+//   reference side: element (sl, column cs, level kk) of tracer tr at
+//       ref + tr*ref_tstride + sl + ncrms*(cs*ref_colmul + kk*ref_levmul)
+//     f, u, w: ref_colmul = 1, ref_levmul = number of columns; rho, rhow, adz, flux: one
+//     column, ref_levmul = 1
+//   private side: element (tile t, column cs + prv_col0, instance-in-tile s, level kk) at
+//       prv + tr*prv_tstride + t*prv_tile_stride + (cs + prv_col0)*chunk + s*nlev + kk
+struct MpdataLayoutJob {
+  void* ref;
+  void* prv;
+  long long ncrms;
+  int ncols;                 // columns of the reference-side array that are converted
+  int nlev;                  // levels converted (nzm)
+  int ntr;
+  long long ref_colmul, ref_levmul, ref_tstride;
+  int slp;                   // instances per tile
+  int ntiles;
+  int prv_col0;              // column shift: u, w start at c = 1 of the private column index
+  long long chunk;           // slp * nlev
+  long long prv_tile_stride, prv_tstride;
+};
+
+hipError_t mpdata_layout_convert(const MpdataLayoutJob& j, int elem_bytes, bool to_private, hipStream_t stream);
+
+#endif

@@ -72,19 +72,47 @@ int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers,
                                   const double* rho, const double* rhow,
                                   const double* adz, double* flux, void* stream);
 
-/* ---- 3. Plan API: device buffers owned by the library (what the OpenACC
+/* ---- 3. Plan API: device state owned by the library (what the OpenACC
  * `enter data pcreate` / `update device` / `update host` directives do,
- * reference :105-107, :241, :662-663). */
+ * reference :105-107, :241, :662-663).  A plan lives on the device that is
+ * current when it is created (every plan call switches to it and back), and
+ * fixes the kernel variant at creation.
+ *
+ * Device layout.  The arrays a caller passes are ALWAYS in the reference
+ * layout above.  Inside an fp64 plan with nz <= 64 the library keeps them in
+ * its own "wave-major" order -- [tile of 64/LPS adjacent instances][column]
+ * [instance][level], LPS = 8/16/32/64 >= nz -- so that every wave streams
+ * contiguous memory; upload / download / import / export
+ * convert on the device.  Other plans (fp32, nz > 64), MPDATA_PLAN_LAYOUT=
+ * reference or mpdata_set_plan_layout(MPDATA_LAYOUT_REFERENCE) keep the
+ * reference layout.  Results do not depend on the layout. */
+#define MPDATA_LAYOUT_REFERENCE 0
+#define MPDATA_LAYOUT_WAVEMAJOR 1
 typedef struct mpdata_plan mpdata_plan;
 int mpdata_plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan);
 int mpdata_plan_upload(mpdata_plan* plan, const double* f, const double* u, const double* w,
                        const double* rho, const double* rhow, const double* adz,
-                       const double* flux);
-int mpdata_plan_run(mpdata_plan* plan);            /* async on the plan's stream */
+                       const double* flux);              /* host arrays; flux may be NULL */
+int mpdata_plan_run(mpdata_plan* plan);            /* all tracers; async on the plan's stream */
+int mpdata_plan_run_tracers(mpdata_plan* plan, int first_tracer, int ntracers); /* a sub-range */
 int mpdata_plan_sync(mpdata_plan* plan);           /* the `!$acc wait` (:237) */
-int mpdata_plan_download(mpdata_plan* plan, double* f, double* flux);
+int mpdata_plan_download(mpdata_plan* plan, double* f, double* flux);  /* host arrays */
 int mpdata_plan_last_kernel_ms(mpdata_plan* plan, double* ms); /* hipEvent time of the last run */
 int mpdata_plan_destroy(mpdata_plan* plan);
+/* Device-side exchange with a plan: reference-layout DEVICE arrays of the plan's precision on
+ * the plan's device, asynchronous on the plan's stream.  Import: NULL pointers are skipped
+ * (the plan keeps what it has); f and flux cover tracers [first_tracer, first_tracer+ntracers).
+ * A caller whose state lives on the device imports once, runs many times, exports when it
+ * needs the field back. */
+int mpdata_plan_import_device(mpdata_plan* plan, const void* f, const void* u, const void* w,
+                              const void* rho, const void* rhow, const void* adz,
+                              const void* flux, int first_tracer, int ntracers);
+int mpdata_plan_export_device(mpdata_plan* plan, void* f, void* flux, int first_tracer, int ntracers);
+/* Run on the caller's stream (hipStream_t as void*; NULL = default stream) from now on. */
+int mpdata_plan_set_stream(mpdata_plan* plan, void* stream);
+int mpdata_plan_layout(const mpdata_plan* plan);   /* MPDATA_LAYOUT_* */
+int mpdata_plan_device(const mpdata_plan* plan);   /* HIP device ordinal */
+int mpdata_set_plan_layout(int layout);            /* default for new plans; returns previous */
 
 /* ---- 4. Synthetic inputs on the device (bench/tests; the reference's init,
  * :645-660, with a portable counter-based generator instead of the

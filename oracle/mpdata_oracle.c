@@ -50,19 +50,22 @@ typedef double real;
 #define R_(x) ((real)(x))
 
 typedef struct {
-  int64_t n;      /* ncrms (leading dimension of every array) */
+  int64_t n;      /* ncrms (leading dimension of every argument array) */
   int nx, nz, nzm;
+  int64_t sn, so; /* scratch arrays: leading dimension and the instance their element 0 holds
+                     (serial: n, 0 = the reference's automatic arrays; OpenMP: a thread's chunk) */
 } dims_t;
 
 /* Fortran-style indexers (1-based k, signed i), sl is 0-based here. */
 #define F_(sl, i, k)   f  [(sl) + d.n * ((int64_t)((i) + 2) + (int64_t)(d.nx + 6) * ((k) - 1))]
 #define U_(sl, i, k)   u  [(sl) + d.n * ((int64_t)((i) + 1) + (int64_t)(d.nx + 5) * ((k) - 1))]
 #define W_(sl, i, k)   w  [(sl) + d.n * ((int64_t)((i) + 1) + (int64_t)(d.nx + 4) * ((k) - 1))]
-#define MX_(sl, i, k)  mx [(sl) + d.n * ((int64_t)(i)       + (int64_t)(d.nx + 2) * ((k) - 1))]
-#define MN_(sl, i, k)  mn [(sl) + d.n * ((int64_t)(i)       + (int64_t)(d.nx + 2) * ((k) - 1))]
-#define UUU_(sl, i, k) uuu[(sl) + d.n * ((int64_t)((i) + 1) + (int64_t)(d.nx + 5) * ((k) - 1))]
-#define WWW_(sl, i, k) www[(sl) + d.n * ((int64_t)((i) + 1) + (int64_t)(d.nx + 4) * ((k) - 1))]
+#define MX_(sl, i, k)  mx [((sl) - d.so) + d.sn * ((int64_t)(i)       + (int64_t)(d.nx + 2) * ((k) - 1))]
+#define MN_(sl, i, k)  mn [((sl) - d.so) + d.sn * ((int64_t)(i)       + (int64_t)(d.nx + 2) * ((k) - 1))]
+#define UUU_(sl, i, k) uuu[((sl) - d.so) + d.sn * ((int64_t)((i) + 1) + (int64_t)(d.nx + 5) * ((k) - 1))]
+#define WWW_(sl, i, k) www[((sl) - d.so) + d.sn * ((int64_t)((i) + 1) + (int64_t)(d.nx + 4) * ((k) - 1))]
 #define K2_(a, sl, k)  a  [(sl) + d.n * (int64_t)((k) - 1)]
+#define KS_(a, sl, k)  a  [((sl) - d.so) + d.sn * (int64_t)((k) - 1)]   /* scratch */
 
 static inline real dmax(real a, real b) { return a > b ? a : b; }
 static inline real dmin(real a, real b) { return a < b ? a : b; }
@@ -82,7 +85,7 @@ typedef struct {
 } scratch_t;
 
 static int scratch_alloc(scratch_t *s, dims_t d) {
-  size_t n = (size_t)d.n;
+  size_t n = (size_t)d.sn;
   s->mx = (real *)malloc(n * (d.nx + 2) * d.nzm * sizeof(real));
   s->mn = (real *)malloc(n * (d.nx + 2) * d.nzm * sizeof(real));
   s->uuu = (real *)malloc(n * (d.nx + 5) * d.nzm * sizeof(real));
@@ -150,13 +153,13 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
   /* :550-560  first-pass update, halo columns -1..nx+2 included */
   for (k = 1; k <= nzm; k++) {
     for (sl = s0; sl < s1; sl++) {
-      K2_(irho, sl, k) = R_(1.0) / K2_(rho, sl, k);
-      K2_(iadz, sl, k) = R_(1.0) / K2_(adz, sl, k);
+      KS_(irho, sl, k) = R_(1.0) / K2_(rho, sl, k);
+      KS_(iadz, sl, k) = R_(1.0) / K2_(adz, sl, k);
     }
     for (i = -1; i <= nxp2; i++)
       for (sl = s0; sl < s1; sl++)
         F_(sl, i, k) = F_(sl, i, k) - (UUU_(sl, i + 1, k) - UUU_(sl, i, k) +
-                                       (WWW_(sl, i, k + 1) - WWW_(sl, i, k)) * K2_(iadz, sl, k)) * K2_(irho, sl, k);
+                                       (WWW_(sl, i, k + 1) - WWW_(sl, i, k)) * KS_(iadz, sl, k)) * KS_(irho, sl, k);
   }
 
   if (last_stage < 4) return;  /* stage-by-stage mode, see mpdata_oracle_advect_stages */
@@ -166,23 +169,23 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
     kb = k - 1 > 1 ? k - 1 : 1;
     /* :569  `2./(kc-kb)` is default-real / integer: exactly 1.0 or 2.0 */
     const real two_over = (real)(2.0f / (float)(kc - kb));
-    for (sl = s0; sl < s1; sl++) K2_(irhow, sl, k) = R_(1.0) / (K2_(rhow, sl, k) * K2_(adz, sl, k));
+    for (sl = s0; sl < s1; sl++) KS_(irhow, sl, k) = R_(1.0) / (K2_(rhow, sl, k) * K2_(adz, sl, k));
     for (i = 0; i <= nxp2; i++)
       for (sl = s0; sl < s1; sl++) {
         const real dd = two_over / K2_(adz, sl, k);
         ib = i - 1;
-        UUU_(sl, i, k) = andiff(F_(sl, ib, k), F_(sl, i, k), U_(sl, i, k), K2_(irho, sl, k)) -
+        UUU_(sl, i, k) = andiff(F_(sl, ib, k), F_(sl, i, k), U_(sl, i, k), KS_(irho, sl, k)) -
                          across(dd * (F_(sl, ib, kc) + F_(sl, i, kc) - F_(sl, ib, kb) - F_(sl, i, kb)),
                                 U_(sl, i, k),
-                                W_(sl, ib, k) + W_(sl, ib, kc) + W_(sl, i, k) + W_(sl, i, kc)) * K2_(irho, sl, k);
+                                W_(sl, ib, k) + W_(sl, ib, kc) + W_(sl, i, k) + W_(sl, i, kc)) * KS_(irho, sl, k);
       }
     for (i = 0; i <= nxp1; i++)
       for (sl = s0; sl < s1; sl++) {
         ib = i - 1; ic = i + 1;
-        WWW_(sl, i, k) = andiff(F_(sl, i, kb), F_(sl, i, k), W_(sl, i, k), K2_(irhow, sl, k)) -
+        WWW_(sl, i, k) = andiff(F_(sl, i, kb), F_(sl, i, k), W_(sl, i, k), KS_(irhow, sl, k)) -
                          across(F_(sl, ic, kb) + F_(sl, ic, k) - F_(sl, ib, kb) - F_(sl, ib, k),
                                 W_(sl, i, k),
-                                U_(sl, i, kb) + U_(sl, i, k) + U_(sl, ic, k) + U_(sl, ic, kb)) * K2_(irho, sl, k);
+                                U_(sl, i, kb) + U_(sl, i, k) + U_(sl, ic, k) + U_(sl, ic, kb)) * KS_(irho, sl, k);
       }
   }
   /* :586  www(:,:,:,1) = 0. */
@@ -210,10 +213,10 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
         ic = i + 1;
         MX_(sl, i, k) = K2_(rho, sl, k) * (MX_(sl, i, k) - F_(sl, i, k)) /
                         (pn(UUU_(sl, ic, k)) + pp(UUU_(sl, i, k)) +
-                         K2_(iadz, sl, k) * (pn(WWW_(sl, i, kc)) + pp(WWW_(sl, i, k))) + eps);
+                         KS_(iadz, sl, k) * (pn(WWW_(sl, i, kc)) + pp(WWW_(sl, i, k))) + eps);
         MN_(sl, i, k) = K2_(rho, sl, k) * (F_(sl, i, k) - MN_(sl, i, k)) /
                         (pp(UUU_(sl, ic, k)) + pn(UUU_(sl, i, k)) +
-                         K2_(iadz, sl, k) * (pp(WWW_(sl, i, kc)) + pn(WWW_(sl, i, k))) + eps);
+                         KS_(iadz, sl, k) * (pp(WWW_(sl, i, kc)) + pn(WWW_(sl, i, k))) + eps);
       }
   }
   if (last_stage < 7) return;  /* stage-by-stage mode, see mpdata_oracle_advect_stages */
@@ -240,7 +243,7 @@ static void advect_range(dims_t d, int64_t s0, int64_t s1, real *f, const real *
     for (i = 1; i <= nx; i++)
       for (sl = s0; sl < s1; sl++)
         F_(sl, i, k) = dmax(R_(0.0), F_(sl, i, k) - (UUU_(sl, i + 1, k) - UUU_(sl, i, k) +
-                                                 (WWW_(sl, i, k + 1) - WWW_(sl, i, k)) * K2_(iadz, sl, k)) * K2_(irho, sl, k));
+                                                 (WWW_(sl, i, k + 1) - WWW_(sl, i, k)) * KS_(iadz, sl, k)) * KS_(irho, sl, k));
 }
 
 /*
@@ -256,23 +259,44 @@ int SYM(mpdata_oracle_advect)(int64_t ncrms, int nx, int nz, real *f, const real
   dims_t d;
   scratch_t sc;
   if (ncrms < 1 || nx < 1 || nz < 3) return -1;
-  d.n = ncrms; d.nx = nx; d.nz = nz; d.nzm = nz - 1;
-  if (scratch_alloc(&sc, d) != 0) { scratch_free(&sc); return -1; }
+  d.n = ncrms; d.nx = nx; d.nz = nz; d.nzm = nz - 1; d.sn = ncrms; d.so = 0;
   if (nthreads <= 1) {
+    if (scratch_alloc(&sc, d) != 0) { scratch_free(&sc); return -1; }
     advect_range(d, 0, ncrms, f, u, w, rho, rhow, adz, flux, sc, 8);
+    scratch_free(&sc);
   } else {
-    const int64_t chunk = 64;
+    /* every thread owns a scratch set of one chunk (allocated and first touched by the thread
+       itself) and walks its share of the chunks */
+    const int64_t chunk = 128;
     const int64_t nchunks = (ncrms + chunk - 1) / chunk;
-    int64_t c;
+    int failed = 0;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(nthreads)
+#pragma omp parallel num_threads(nthreads)
 #endif
-    for (c = 0; c < nchunks; c++) {
-      int64_t s0 = c * chunk, s1 = s0 + chunk < ncrms ? s0 + chunk : ncrms;
-      advect_range(d, s0, s1, f, u, w, rho, rhow, adz, flux, sc, 8);
+    {
+      dims_t dl = d;
+      scratch_t sl_;
+      int64_t c;
+      dl.sn = chunk;
+      if (scratch_alloc(&sl_, dl) != 0) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+        failed = 1;
+      } else {
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (c = 0; c < nchunks; c++) {
+          int64_t s0 = c * chunk, s1 = s0 + chunk < ncrms ? s0 + chunk : ncrms;
+          dl.so = s0;
+          advect_range(dl, s0, s1, f, u, w, rho, rhow, adz, flux, sl_, 8);
+        }
+      }
+      scratch_free(&sl_);
     }
+    if (failed) return -1;
   }
-  scratch_free(&sc);
   return 0;
 }
 
@@ -293,7 +317,7 @@ int SYM(mpdata_oracle_advect_stages)(int64_t ncrms, int nx, int nz, int last_sta
   dims_t d;
   scratch_t sc;
   if (ncrms < 1 || nx < 1 || nz < 3 || last_stage < 1 || last_stage > 8) return -1;
-  d.n = ncrms; d.nx = nx; d.nz = nz; d.nzm = nz - 1;
+  d.n = ncrms; d.nx = nx; d.nz = nz; d.nzm = nz - 1; d.sn = ncrms; d.so = 0;
   sc.mx = mx; sc.mn = mn; sc.uuu = uuu; sc.www = www;
   sc.iadz = (real *)malloc((size_t)ncrms * d.nzm * sizeof(real));
   sc.irho = (real *)malloc((size_t)ncrms * d.nzm * sizeof(real));

@@ -1,0 +1,159 @@
+"""GPU parity tests of the plan API in its wave-major device layout (the kernel of
+mpdata_kernel_wm_body.h + the layout conversions of mpdata_layout.hip), through the C-ABI:
+plan_create / upload / run / download with HOST arrays in the reference layout, and
+import_device / run_tracers / export_device with DEVICE arrays.
+
+Bars as in test_hip_parity.py: EXACT -> f bit-identical to the oracle and to the reference's
+golden outputs, flux within 1e-13 relative (other summation order); FAST -> max|d| < 1e-12 on
+conditioned inputs, rel-L1 < 1e-14 on reference-raw inputs.
+"""
+import numpy as np
+import pytest
+
+from util import golden_cases, load_golden, max_abs, to_dev, to_host
+
+pytestmark = pytest.mark.gpu
+
+TOL_ABS = 1e-12
+TOL_RELL1 = 1e-14
+FLUX_RTOL = 1e-13
+
+
+def flux_close(flux, flux_ref):
+    nzm = flux.shape[1] - 1
+    a, b = flux[:, :nzm], flux_ref[:, :nzm]
+    ok = np.all(np.abs(a - b) <= FLUX_RTOL * np.maximum(1.0, np.abs(b)))
+    return bool(ok) and np.array_equal(flux[:, nzm], flux_ref[:, nzm])
+
+
+@pytest.fixture(scope="module")
+def M(mpdata):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    yield mpdata
+    mpdata.set_variant(mpdata.VARIANT_EXACT)
+    mpdata.set_plan_layout(mpdata.LAYOUT_WAVEMAJOR)
+
+
+def run_plan_host(M, inp, ntr=1):
+    """upload -> run -> download on host arrays; returns (f, flux)."""
+    ncrms, nxp6, nzm = inp["f"].shape[:3]
+    p = M.Plan(ncrms, nxp6 - 6, nzm + 1, ntr)
+    assert p.layout == M.LAYOUT_WAVEMAJOR
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run()
+    p.sync()
+    f = np.empty_like(inp["f"], order="F")
+    flux = np.empty_like(inp["flux"], order="F")
+    p.download(f, flux)
+    p.close()
+    return f, flux
+
+
+def assert_parity(M, oracle, variant, dist, f, flux, f_ref, flux_ref):
+    if variant == M.VARIANT_EXACT:
+        assert np.array_equal(f, f_ref), f"f differs: max|d|={max_abs(f, f_ref):.3e}"
+        assert flux_close(flux, flux_ref), f"flux differs: max|d|={max_abs(flux, flux_ref):.3e}"
+    elif dist == oracle.DIST_CONDITIONED:
+        assert max_abs(f, f_ref) < TOL_ABS
+        assert max_abs(flux, flux_ref) < TOL_ABS
+    else:
+        assert oracle.rel_l1(f, f_ref) < TOL_RELL1
+        nzm = flux.shape[1] - 1
+        assert oracle.rel_l1(flux[:, :nzm], flux_ref[:, :nzm]) < TOL_RELL1
+        assert np.array_equal(flux[:, nzm], flux_ref[:, nzm])
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_wavemajor_plan_reproduces_reference_golden_bitwise(M, oracle, case):
+    M.set_variant(M.VARIANT_EXACT)
+    inp = oracle.make_inputs(case["ncrms"], case["nx"], case["nz"], seed=case["seed"], dist=case["dist"])
+    f_ref, flux_ref = load_golden(case)
+    f, flux = run_plan_host(M, inp)
+    assert np.array_equal(f, f_ref), f"max|df|={max_abs(f, f_ref):.3e}"
+    assert flux_close(flux, flux_ref), f"max|dflux|={max_abs(flux, flux_ref):.3e}"
+
+
+# (ncrms, nx, nz): every LPS (8/16/32/64 lanes per instance), ragged ncrms (partial last tile,
+# fewer tiles than a workgroup holds), odd nx (a last pair with one column), the smallest
+# shapes the routine is defined for, nz at the top of each LPS class, the shipped size
+SHAPES = [(64, 32, 28), (48, 32, 58), (1, 1, 3), (3, 1, 3), (7, 2, 4), (5, 3, 8), (19, 5, 9), (33, 7, 16),
+          (37, 32, 17), (129, 9, 32), (21, 33, 33), (10, 6, 64), (131, 4, 28), (258, 31, 28), (100, 66, 28)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+@pytest.mark.parametrize("dist", [1, 3])
+def test_wavemajor_plan_shapes(M, oracle, shape, variant, dist):
+    var = M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST
+    M.set_variant(var)
+    inp = oracle.make_inputs(*shape, seed=11, dist=dist)
+    f, flux = run_plan_host(M, inp)
+    f_ref, flux_ref = oracle.advect(inp, nthreads=4)
+    assert_parity(M, oracle, var, dist, f, flux, f_ref, flux_ref)
+    # output contract: columns -2 and nx+3 untouched, flux(:,nz) untouched
+    assert np.array_equal(f[:, 0], inp["f"][:, 0]) and np.array_equal(f[:, -1], inp["f"][:, -1])
+    assert np.array_equal(flux[:, -1], inp["flux"][:, -1])
+
+
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_wavemajor_tracer_batch_and_subranges(M, oracle, variant):
+    """T tracers sharing u, w, rho, rhow, adz == T single-tracer calls of the oracle; a sub-range
+    run touches only its tracers; device import / export round-trips."""
+    import torch
+    var = M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST
+    M.set_variant(var)
+    ncrms, nx, nz, T = 96, 32, 28, 5
+    base = oracle.make_inputs(ncrms, nx, nz, seed=5, dist=1)
+    fs = [oracle.make_inputs(ncrms, nx, nz, seed=50 + t, dist=1)["f"] for t in range(T)]
+    refs = [oracle.advect(dict(base, f=fs[t].copy()), nthreads=4) for t in range(T)]
+    inp = dict(base)
+    inp["f"] = np.asfortranarray(np.stack(fs, axis=-1))
+    inp["flux"] = np.asfortranarray(np.stack([base["flux"]] * T, axis=-1))
+    f, flux = run_plan_host(M, inp, ntr=T)
+    for t in range(T):
+        assert_parity(M, oracle, var, 1, f[..., t], flux[..., t], refs[t][0], refs[t][1])
+    # device import, run tracers 1..2 only, export
+    p = M.Plan(ncrms, nx, nz, T)
+    d = {k: to_dev(v) for k, v in inp.items()}
+    p.import_device(d["f"], d["u"], d["w"], d["rho"], d["rhow"], d["adz"], d["flux"])
+    p.run(1, 2)
+    fo, flo = torch.empty_like(d["f"]), torch.empty_like(d["flux"])
+    p.export_device(fo, flo)
+    p.sync()
+    fo, flo = to_host(fo), to_host(flo)
+    for t in range(T):
+        if t in (1, 2):
+            assert_parity(M, oracle, var, 1, fo[..., t], flo[..., t], refs[t][0], refs[t][1])
+        else:   # untouched: the import/export round trip is the identity
+            assert np.array_equal(fo[..., t], inp["f"][..., t])
+            assert np.array_equal(flo[..., t], inp["flux"][..., t])
+    p.close()
+
+
+def test_layouts_agree_bitwise(M, oracle):
+    """The same plan calls in the reference layout (x-march kernel) and the wave-major layout:
+    EXACT bit-identical (same arithmetic, same order); FAST equal up to the compiler's choice of
+    FMA contractions in the two kernels (reference metric, raw inputs)."""
+    inp = oracle.make_inputs(200, 32, 28, seed=3, dist=3)
+    for var in (M.VARIANT_EXACT, M.VARIANT_FAST):
+        M.set_variant(var)
+        f1, fl1 = run_plan_host(M, inp)
+        M.set_plan_layout(M.LAYOUT_REFERENCE)
+        try:
+            ncrms, nxp6, nzm = inp["f"].shape[:3]
+            p = M.Plan(ncrms, nxp6 - 6, nzm + 1, 1)
+            assert p.layout == M.LAYOUT_REFERENCE
+            p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+            p.run(); p.sync()
+            f2 = np.empty_like(inp["f"], order="F"); fl2 = np.empty_like(inp["flux"], order="F")
+            p.download(f2, fl2)
+            p.close()
+        finally:
+            M.set_plan_layout(M.LAYOUT_WAVEMAJOR)
+        if var == M.VARIANT_EXACT:
+            assert np.array_equal(f1, f2)
+            assert np.array_equal(fl1, fl2)
+        else:
+            assert oracle.rel_l1(f1, f2) < TOL_RELL1
+            assert oracle.rel_l1(fl1[:, :-1], fl2[:, :-1]) < TOL_RELL1

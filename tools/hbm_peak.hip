@@ -20,6 +20,23 @@ __global__ void __launch_bounds__(256) k_inplace(d4* o, size_t n4) {
 __global__ void __launch_bounds__(256) k_mix(const d2* a, const d2* b, const d2* c, d2* o, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = a[i] + b[i] + c[i];
 }
+// one workgroup per contiguous 16-KB piece (4 x 16 B per thread, all loads first); o may alias a
+template <int NT>
+__global__ void __launch_bounds__(256) k_mix4(const d2* a, const d2* b, const d2* c, d2* o, size_t n) {
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  d2 x[4], y[4], z[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const size_t i = base + j * 256;
+    if (NT) { x[j] = __builtin_nontemporal_load(a + i); y[j] = __builtin_nontemporal_load(b + i); z[j] = __builtin_nontemporal_load(c + i); }
+    else { x[j] = a[i]; y[j] = b[i]; z[j] = c[i]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const size_t i = base + j * 256;
+    if (NT) __builtin_nontemporal_store(x[j] + y[j] + z[j], o + i); else o[i] = x[j] + y[j] + z[j];
+  }
+}
 int main(int argc, char** argv) {
   // argv[1] = 1: stagger the four arrays by 256 B each (different offsets modulo 1 KiB)
   const size_t stag = argc > 1 && argv[1][0] == '1' ? 256 : 0;
@@ -48,6 +65,20 @@ int main(int argc, char** argv) {
       const double moved = (double)bytes * (which == 0 ? 3 : which == 1 ? 2 : which == 2 ? 4 : 2);
       printf("grid %6d %-10s best %.3f ms %.2f TB/s   mean(steady) %.3f ms %.2f TB/s\n", grid, which == 0 ? "read 3R" : which == 1 ? "copy 1R:1W" : which == 2 ? "mix 3R:1W" : "in place 1R:1W", best, moved / (best * 1e-3) / 1e12, sum / cnt, moved / (sum / cnt * 1e-3) / 1e12);
     }
+  }
+  for (int which = 0; which < 4; ++which) {
+    float sum = 0; int cnt = 0;
+    d2* dst = (which & 1) ? a : o;
+    for (int r = 0; r < 60; ++r) {
+      (void)hipEventRecord(e0);
+      if (which < 2) hipLaunchKernelGGL(k_mix4<0>, dim3((unsigned)(n / 1024)), dim3(256), 0, 0, a, b, c, dst, n);
+      else hipLaunchKernelGGL(k_mix4<1>, dim3((unsigned)(n / 1024)), dim3(256), 0, 0, a, b, c, dst, n);
+      (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+      if (r >= 20) { sum += ms; ++cnt; }
+    }
+    printf("mix4 3R:1W one 16-KB piece per workgroup, %s, %s: mean(steady) %.3f ms %.2f TB/s\n", which < 2 ? "plain" : "nontemporal",
+           (which & 1) ? "in place (o = a)" : "separate output", sum / cnt, (double)bytes * 4 / (sum / cnt * 1e-3) / 1e12);
   }
   return 0;
 }

@@ -1,0 +1,161 @@
+// Diagnostic microbenchmark: data-movement skeleton of the "wave-major" private layout
+// (DESIGN.md section 4.6): every wave owns SLP adjacent instances and streams its own linear
+// image  [tile][column][instance-in-tile][level]  of f, u, w -- no workgroup barrier, no LDS
+// transpose -- through a per-wave LDS-DMA ring, and stores the column back from registers.
+// Variants: 16-B DMA of column PAIRS vs 4-B DMA of single columns, ring depth, waves per
+// workgroup, in-place stores, and register-staged loads (no LDS at all).  No arithmetic.
+// Not part of the product.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long long bytes) {
+  const long long lim = 0xFFFFFFF0ll;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)(unsigned)(bytes > lim ? lim : bytes), 0x00020000);
+}
+#define OOB 0xFFFFFFF8u
+
+// MODE 0: 16-B DMA, one instruction per array and column PAIR (864 B), ring of NS pairs
+// MODE 1: 4-B DMA, two instructions per array and column (432 B), ring of NS columns
+// MODE 2: register loads (buffer_load_dwordx2 per lane), software pipeline depth NS columns
+template <int MODE, int NS, int WPB, int LA = 0, int SA = 0>
+__global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, const char* w, char* fo,
+                                                  int ntiles, int ncol, int chunkB, long long tileB) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x * WPB + wave;
+  if (tile >= ntiles) return;
+  // descriptors relative to this wave's tile (arrays may exceed 4 GiB)
+  const __amdgpu_buffer_rsrc_t rf = make_rsrc(f + tile * tileB, tileB);
+  const __amdgpu_buffer_rsrc_t ru = make_rsrc(u + tile * tileB, tileB);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(w + tile * tileB, tileB);
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(fo + tile * tileB, tileB);
+  const unsigned st_off = lane * 8 < chunkB ? lane * 8 : OOB;
+  if constexpr (MODE == 0) {
+    __shared__ double lds[WPB * NS * 3 * 128];
+    double* my = lds + wave * NS * 3 * 128;
+    const unsigned v = lane * 16 < 2 * chunkB ? lane * 16 : OOB;
+    const int npair = ncol / 2;
+    auto dma = [&](int p) __attribute__((always_inline)) {
+      if (p >= npair) p = npair - 1;
+      double* d = my + (p % NS) * 3 * 128;
+      const unsigned so = (unsigned)(p * 2 * chunkB);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_ptr_t)d, 16, (int)v, (int)so, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(d + 128), 16, (int)v, (int)so, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(d + 256), 16, (int)v, (int)so, 0, LA);
+    };
+    for (int p = 0; p < NS - 1; ++p) {
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{0, 0}, ro, (int)OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{0, 0}, ro, (int)OOB, 0, 0);
+      dma(p);
+    }
+    for (int p = 0; p < npair; ++p) {
+      static_assert(NS >= 2 && NS <= 4, "");
+      if (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (NS == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      if (NS == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      const double* s = my + (p % NS) * 3 * 128;
+      const int kl = lane * 8 < chunkB ? lane : 0;
+      const double a0 = s[kl] + s[128 + kl] + s[256 + kl];
+      const double a1 = s[chunkB / 8 + kl] + s[128 + chunkB / 8 + kl] + s[256 + chunkB / 8 + kl];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)st_off, (int)(p * 2 * chunkB), SA);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)st_off, (int)((p * 2 + 1) * chunkB), SA);
+      dma(p + NS - 1);
+    }
+  } else if constexpr (MODE == 1) {
+    __shared__ double lds[WPB * NS * 3 * 64];
+    double* my = lds + wave * NS * 3 * 64;
+    const unsigned v0 = lane * 4, v1 = 256 + lane * 4 < chunkB ? 256 + lane * 4 : OOB;
+    auto dma = [&](int c) __attribute__((always_inline)) {
+      if (c >= ncol) c = ncol - 1;
+      double* d = my + (c % NS) * 3 * 64;
+      const unsigned so = (unsigned)(c * chunkB);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_ptr_t)d, 4, (int)v0, (int)so, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_ptr_t)(d + 32), 4, (int)v1, (int)so, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(d + 64), 4, (int)v0, (int)so, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(d + 96), 4, (int)v1, (int)so, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(d + 128), 4, (int)v0, (int)so, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(d + 160), 4, (int)v1, (int)so, 0, LA);
+    };
+    for (int c = 0; c < NS - 1; ++c) {
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{0, 0}, ro, (int)OOB, 0, 0);
+      dma(c);
+    }
+    for (int c = 0; c < ncol; ++c) {
+      static_assert(NS >= 3 && NS <= 5, "");
+      if (NS == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      if (NS == 4) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+      if (NS == 5) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+      const double* s = my + (c % NS) * 3 * 64;
+      const int kl = lane * 8 < chunkB ? lane : 0;
+      const double a0 = s[kl] + s[64 + kl] + s[128 + kl];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)st_off, (int)(c * chunkB), SA);
+      dma(c + NS - 1);
+    }
+  } else {
+    // register-staged: NS columns of (f,u,w) in flight per lane
+    double rf_[NS], ru_[NS], rw_[NS];
+    auto ld = [&](int c, int j) __attribute__((always_inline)) {
+      if (c >= ncol) c = ncol - 1;
+      const unsigned so = (unsigned)(c * chunkB);
+      rf_[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rf, (int)st_off, (int)so, LA));
+      ru_[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ru, (int)st_off, (int)so, LA));
+      rw_[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rw, (int)st_off, (int)so, LA));
+    };
+#pragma unroll
+    for (int j = 0; j < NS; ++j) ld(j, j);
+    for (int c0 = 0; c0 < ncol; c0 += NS) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const double a = rf_[j] + ru_[j] + rw_[j];
+        if (c0 + j < ncol)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), ro, (int)st_off, (int)((c0 + j) * chunkB), SA);
+        ld(c0 + j + NS, j);
+      }
+    }
+  }
+}
+
+template <int MODE, int NS, int WPB, int LA = 0, int SA = 0>
+void run(const char* f, const char* u, const char* w, char* fo, int ntiles, int ncol, int chunkB, long long tileB, const char* tag) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int blocks = (ntiles + WPB - 1) / WPB;
+  // occupancy as in the real kernel (128 VGPRs: 16 waves per CU): pad every wave to 10 KB of LDS
+  const int stat = MODE == 0 ? NS * 3 * 1024 : MODE == 1 ? NS * 3 * 512 : 0;
+  const int dyn = stat < 10240 ? WPB * (10240 - stat) : 0;
+  for (int r = 0; r < 60; ++r)
+    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB);
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < 60; ++r)
+    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 60;
+  const double bytes = (double)ntiles * ncol * chunkB * 4;
+  printf("%-10s LA %d SA %d mode %d ring %d waves/wg %d tileB %lld: %.3f ms  %.2f TB/s (err %d)\n", tag, LA, SA, MODE, NS, WPB, tileB, ms,
+         bytes / (ms * 1e-3) / 1e12, (int)hipGetLastError());
+}
+
+int main(int argc, char** argv) {
+  const int ntiles = 32768, ncol = 38;
+  for (int chunkB : {432, 448, 512}) {
+    const long long tileB = 38ll * chunkB;
+    const size_t n = (size_t)ntiles * tileB;
+    char *f, *u, *w, *fo;
+    (void)hipMalloc(&f, n + 8192); (void)hipMalloc(&u, n + 8192); (void)hipMalloc(&w, n + 8192); (void)hipMalloc(&fo, n + 8192);
+    (void)hipMemset(f, 0, n); (void)hipMemset(u, 0, n); (void)hipMemset(w, 0, n); (void)hipMemset(fo, 0, n);
+    const char* uu = u; const char* ww = w;
+    printf("---- chunk %d B (TB/s counts the bytes actually moved; x %.3f = algorithmic at 432 B)\n", chunkB, 432.0 / chunkB);
+    run<0, 3, 1>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
+    run<0, 3, 4>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
+    run<0, 3, 4, 2, 0>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
+    run<0, 3, 4, 0, 2>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
+    run<0, 3, 4, 2, 2>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
+    run<2, 4, 4, 0, 0>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
+    run<2, 4, 4, 2, 2>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
+    (void)hipFree(f); (void)hipFree(u); (void)hipFree(w); (void)hipFree(fo);
+  }
+  return 0;
+}
