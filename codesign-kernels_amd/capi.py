@@ -84,6 +84,19 @@ def lib():
             getattr(L, name).argtypes = [vp]
         L.mpdata_set_plan_layout.restype = ci
         L.mpdata_set_plan_layout.argtypes = [ci]
+        L.mpdata_plan_create_multi.restype = ci
+        L.mpdata_plan_create_multi.argtypes = [i64, ci, ci, ci, ci, ctypes.POINTER(vp)]
+        L.mpdata_plan_create_multi_devices.restype = ci
+        L.mpdata_plan_create_multi_devices.argtypes = [i64, ci, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(vp)]
+        L.mpdata_shard_range.restype = None
+        L.mpdata_shard_range.argtypes = [i64, ci, ci, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        L.mpdata_plan_ngpus.restype = ci
+        L.mpdata_plan_ngpus.argtypes = [vp]
+        L.mpdata_plan_shard.restype = ci
+        L.mpdata_plan_shard.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        L.mpdata_plan_transfer_stats.restype = ci
+        L.mpdata_plan_transfer_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                                 ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(ci)]
         L.mpdata_fill_synthetic_device.restype = ci
         L.mpdata_fill_synthetic_device.argtypes = [dp, ci, i64, i64, i64, i64, ctypes.c_uint64, ci, vp]
         L.mpdata_pack_shard_device.restype = ci
@@ -142,6 +155,13 @@ def set_tile(t):
 def set_plan_layout(layout):
     """Default device layout of new plans (LAYOUT_*); returns the previous one."""
     return lib().mpdata_set_plan_layout(int(layout))
+
+
+def shard_range(ncrms, ngpus, g):
+    """(sl0, nloc) of GPU g's contiguous block of CRM instances (mpdata_shard_range)."""
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    lib().mpdata_shard_range(int(ncrms), int(ngpus), int(g), ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 def device_count():
@@ -312,14 +332,48 @@ class Plan:
     the boundary in the reference layout; the plan keeps them in its own layout
     (`layout`: LAYOUT_WAVEMAJOR for fp64 with nz <= 64, include/mpdata_hip.h 3)."""
 
-    def __init__(self, ncrms, nx, nz, ntracers=1, dtype=np.float64):
+    def __init__(self, ncrms, nx, nz, ntracers=1, dtype=np.float64, ngpus=None, devices=None):
+        """ngpus / devices: a multi-GPU plan (include/mpdata_hip.h section 3b) -- the problem
+        is cut into contiguous ncrms blocks, one per GPU; upload scatters, download gathers."""
         self._p = ctypes.c_void_p()
         self._dt = np.dtype(dtype).type
         if self._dt not in (np.float64, np.float32):
             raise MpdataError(-1, f"Plan: dtype {dtype} is neither float64 nor float32")
         self._sfx = "" if self._dt == np.float64 else "_f32"
         self.dims = (int(ncrms), int(nx), int(nz), int(ntracers))
-        _check(getattr(lib(), "mpdata_plan_create" + self._sfx)(ncrms, nx, nz, ntracers, ctypes.byref(self._p)))
+        if ngpus is None and devices is None:
+            _check(getattr(lib(), "mpdata_plan_create" + self._sfx)(ncrms, nx, nz, ntracers, ctypes.byref(self._p)))
+        else:
+            if self._dt != np.float64:
+                raise MpdataError(-1, "multi-GPU plans are fp64")
+            if devices is not None:
+                arr = (ctypes.c_int * len(devices))(*devices)
+                _check(lib().mpdata_plan_create_multi_devices(ncrms, nx, nz, ntracers, len(devices), arr,
+                                                              ctypes.byref(self._p)))
+            else:
+                _check(lib().mpdata_plan_create_multi(ncrms, nx, nz, ntracers, int(ngpus), ctypes.byref(self._p)))
+
+    @property
+    def ngpus(self):
+        return lib().mpdata_plan_ngpus(self._p)
+
+    def shards(self):
+        """[(device, sl0, nloc)] of the plan's GPUs."""
+        out = []
+        for g in range(self.ngpus):
+            d, a, b = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64()
+            _check(lib().mpdata_plan_shard(self._p, g, ctypes.byref(d), ctypes.byref(a), ctypes.byref(b)))
+            out.append((d.value, a.value, b.value))
+        return out
+
+    def transfer_stats(self):
+        """Multi-GPU plans: seconds and bytes per peer link of the last upload / download."""
+        ss, gs = ctypes.c_double(), ctypes.c_double()
+        sb, gb, tr = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        _check(lib().mpdata_plan_transfer_stats(self._p, ctypes.byref(ss), ctypes.byref(gs), ctypes.byref(sb),
+                                                ctypes.byref(gb), ctypes.byref(tr)))
+        return {"scatter_s": ss.value, "gather_s": gs.value, "scatter_bytes_per_peer": sb.value,
+                "gather_bytes_per_peer": gb.value, "transport": ("rccl", "p2p", "direct")[tr.value]}
 
     @property
     def layout(self):

@@ -10,11 +10,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "mpdata_args.h"
 #include "mpdata_hip.h"
 #include "mpdata_layout.h"
+#include "mpdata_multi.h"
 
 namespace mpdata_exact {
 int max_tile_id();
@@ -45,6 +50,17 @@ int set_err(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
+}  // namespace
+int mpdata_internal_set_err(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+namespace {
 int hip_err(hipError_t e, const char* what) {
   return set_err((int)e, "%s: %s", what, hipGetErrorString(e));
 }
@@ -345,6 +361,7 @@ struct mpdata_plan {
   hipEvent_t ev0, ev1;
   bool uploaded, ran;
   unsigned runs;   // launches so far (serpentine tile order)
+  mpdata_multi* multi;  // != null: a multi-GPU plan (mpdata_multi.hip); nothing else above is used
 };
 
 namespace {
@@ -546,6 +563,11 @@ static int plan_upload(mpdata_plan* p, const void* f, const void* u, const void*
   int rc = plan_check(p, eb);
   if (rc) return rc;
   if (!f || !u || !w || !rho || !rhow || !adz) return set_err(MPDATA_EINVAL, "null array pointer");
+  if (p->multi) {
+    rc = mpdata_multi_upload(p->multi, f, u, w, rho, rhow, adz, flux);
+    if (!rc) p->uploaded = true;
+    return rc;
+  }
   DevGuard g(p->device);
   // flux is intent(out) in the reference but its level nz is never written
   // (reference :541, :624 touch 1..nzm only): carry the caller's values over
@@ -576,6 +598,7 @@ int mpdata_plan_import_device(mpdata_plan* p, const void* f, const void* u, cons
                               const void* rhow, const void* adz, const void* flux, int first_tracer,
                               int ntracers) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (p->multi) return set_err(MPDATA_EUNSUPPORTED, "device import into a multi-GPU plan: use mpdata_plan_shard_plan()");
   int rc = tracer_range(p, first_tracer, ntracers);
   if (rc) return rc;
   DevGuard g(p->device);
@@ -587,6 +610,7 @@ int mpdata_plan_import_device(mpdata_plan* p, const void* f, const void* u, cons
 
 int mpdata_plan_export_device(mpdata_plan* p, void* f, void* flux, int first_tracer, int ntracers) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (p->multi) return set_err(MPDATA_EUNSUPPORTED, "device export from a multi-GPU plan: use mpdata_plan_shard_plan()");
   int rc = tracer_range(p, first_tracer, ntracers);
   if (rc) return rc;
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_export_device before upload / import");
@@ -599,6 +623,11 @@ int mpdata_plan_run_tracers(mpdata_plan* p, int first, int count) {
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run before mpdata_plan_upload");
   int rc = tracer_range(p, first, count);
   if (rc) return rc;
+  if (p->multi) {
+    rc = mpdata_multi_run(p->multi, first, count);
+    if (!rc) p->ran = true;
+    return rc;
+  }
   DevGuard g(p->device);
   HIP_TRY(hipEventRecord(p->ev0, p->stream));
   if (p->layout == MPDATA_LAYOUT_WAVEMAJOR) {
@@ -641,6 +670,7 @@ int mpdata_plan_run(mpdata_plan* p) {
 
 int mpdata_plan_sync(mpdata_plan* p) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (p->multi) return mpdata_multi_sync(p->multi);
   DevGuard g(p->device);
   HIP_TRY(hipStreamSynchronize(p->stream));
   return 0;
@@ -650,6 +680,7 @@ static int plan_download(mpdata_plan* p, void* f, void* flux, int eb) {
   int rc = plan_check(p, eb);
   if (rc) return rc;
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_download before upload");
+  if (p->multi) return mpdata_multi_download(p->multi, f, flux);
   DevGuard g(p->device);
   rc = plan_export(p, f, flux, 0, p->ntracers, false);
   if (rc) return rc;
@@ -662,6 +693,7 @@ int mpdata_plan_download_f32(mpdata_plan* p, float* f, float* flux) { return pla
 int mpdata_plan_last_kernel_ms(mpdata_plan* p, double* ms) {
   if (!p || !ms) return set_err(MPDATA_EINVAL, "null argument");
   if (!p->ran) return set_err(MPDATA_ESTATE, "no run recorded");
+  if (p->multi) return mpdata_multi_last_kernel_ms(p->multi, ms);
   DevGuard g(p->device);
   HIP_TRY(hipEventSynchronize(p->ev1));
   float t = 0.f;
@@ -672,6 +704,7 @@ int mpdata_plan_last_kernel_ms(mpdata_plan* p, double* ms) {
 
 int mpdata_plan_set_stream(mpdata_plan* p, void* stream) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (p->multi) return set_err(MPDATA_EUNSUPPORTED, "a multi-GPU plan runs on its own streams, one per device");
   DevGuard g(p->device);
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (p->own_stream) (void)hipStreamDestroy(p->stream);
@@ -687,8 +720,66 @@ int mpdata_set_plan_layout(int layout) {
   return prev;
 }
 
+// ---- multi-GPU plans (mpdata_multi.hip): the same handle type; upload / run / run_tracers /
+// sync / download / last_kernel_ms / destroy dispatch to the per-device plans.
+static int plan_create_multi(int64_t ncrms, int nx, int nz, int ntracers, int ngpus, const int* devices,
+                             mpdata_plan** plan, int eb) {
+  if (!plan) return set_err(MPDATA_EINVAL, "null plan pointer");
+  *plan = nullptr;
+  int rc = validate(ncrms, nx, nz, ntracers);
+  if (rc) return rc;
+  mpdata_plan* p = (mpdata_plan*)calloc(1, sizeof(mpdata_plan));
+  if (!p) return set_err(MPDATA_EINVAL, "out of host memory");
+  p->ncrms = ncrms; p->nx = nx; p->nz = nz; p->ntracers = ntracers; p->eb = eb;
+  p->variant = variant(); p->device = -1; p->layout = -1;
+  p->sz = sizes_of(ncrms, nx, nz, ntracers);
+  rc = mpdata_multi_create(ncrms, nx, nz, ntracers, ngpus, devices, eb, &p->multi);
+  if (rc) { free(p); return rc; }
+  *plan = p;
+  return 0;
+}
+int mpdata_plan_create_multi(int64_t ncrms, int nx, int nz, int ntracers, int ngpus, mpdata_plan** plan) {
+  // MPDATA_MULTI_DEVICES="0,0,1": explicit device list (tests on a one-GPU box repeat a device)
+  const char* e = getenv("MPDATA_MULTI_DEVICES");
+  if (e && *e) {
+    int devs[64], n = 0;
+    for (const char* q = e; *q && n < 64;) {
+      devs[n++] = atoi(q);
+      while (*q && *q != ',') ++q;
+      if (*q == ',') ++q;
+    }
+    if (n >= ngpus) return plan_create_multi(ncrms, nx, nz, ntracers, ngpus, devs, plan, 8);
+  }
+  return plan_create_multi(ncrms, nx, nz, ntracers, ngpus, nullptr, plan, 8);
+}
+int mpdata_plan_create_multi_devices(int64_t ncrms, int nx, int nz, int ntracers, int ngpus, const int* devices,
+                                     mpdata_plan** plan) {
+  return plan_create_multi(ncrms, nx, nz, ntracers, ngpus, devices, plan, 8);
+}
+int mpdata_plan_ngpus(const mpdata_plan* p) { return !p ? MPDATA_EINVAL : (p->multi ? mpdata_multi_ngpus(p->multi) : 1); }
+int mpdata_plan_shard(const mpdata_plan* p, int g, int* device, int64_t* sl0, int64_t* nloc) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (p->multi) return mpdata_multi_info(p->multi, g, device, sl0, nloc);
+  if (g != 0) return set_err(MPDATA_EINVAL, "shard %d of a single-GPU plan", g);
+  if (device) *device = p->device;
+  if (sl0) *sl0 = 0;
+  if (nloc) *nloc = p->ncrms;
+  return 0;
+}
+int mpdata_plan_transfer_stats(const mpdata_plan* p, double* scatter_s, double* gather_s, int64_t* scatter_bytes_per_peer,
+                               int64_t* gather_bytes_per_peer, int* transport) {
+  if (!p || !p->multi) return set_err(MPDATA_EINVAL, "not a multi-GPU plan");
+  mpdata_multi_stats(p->multi, scatter_s, gather_s, scatter_bytes_per_peer, gather_bytes_per_peer, transport);
+  return 0;
+}
+
 int mpdata_plan_destroy(mpdata_plan* p) {
   if (!p) return 0;
+  if (p->multi) {
+    const int rc = mpdata_multi_destroy(p->multi);
+    free(p);
+    return rc;
+  }
   DevGuard g(p->device);
   arena_free(p->arena);
   void* bufs[7] = {p->pf, p->pu, p->pw, p->pkc, p->pflux, p->stage, p->flux_ref};
@@ -701,35 +792,60 @@ int mpdata_plan_destroy(mpdata_plan* p) {
   return 0;
 }
 
-// Host-array call.  Optionally streamed in chunks of instances: for each chunk the strided
-// slabs of every array go host -> device (2-D copies: the chunk is cw*8 bytes of every
-// ncrms*8-byte row), the kernel advects the chunk as a problem of its own (leading
-// dimension cw), f and flux come back -- on two streams with two sets of device buffers
-// (the reference's OpenACC routine spends 72 % + 10 % of its GPU
-// time in exactly these copies, results/advect.pgiacc.17.7-nvprof:18-19).
+// Host-array call = the drop-in for `call advect_scalar2D_openacc_N(f,u,w,rho,rhow,flux)` with
+// its `!$acc update device / host` traffic inside (reference :107, :241).  The reference spends
+// 72 % + 10 % of its GPU time in exactly these copies (results/advect.pgiacc.17.7-nvprof:18-19).
+// The ncrms axis is cut into chunks and pipelined over three streams and three device buffer
+// sets: chunk c+1 goes host -> device (2-D copies: a chunk is cw*8 bytes of every ncrms*8-byte
+// row) while chunk c is advected (a problem of its own, leading dimension cw) and chunk c-1
+// comes back.  A copy from / to PAGEABLE host memory blocks its calling thread while the runtime
+// stages it through pinned buffers (at full PCIe rate once the pages are warm, measured 56 GB/s),
+// so the device -> host leg is driven by a second host thread: both PCIe directions are then
+// busy at once without page-locking anything.  Page-locking the caller's arrays for one call
+// does not pay (hipHostRegister: 20 ms per 538 MB, tools/h2d_rate.hip, against 10 ms to copy
+// them); MPDATA_HOST_PIN=1 does it anyway, and arrays the CALLER has registered are simply
+// used as they are (the copies are then true asynchronous DMA).
+// MPDATA_HOST_CHUNK=<instances per chunk> (default ncrms/8, at least 1024, a multiple of 64).
 namespace {
 struct ChunkBufs {
   Arena arena;
   double *f = nullptr, *u = nullptr, *w = nullptr, *rho = nullptr, *rhow = nullptr, *adz = nullptr, *flux = nullptr;
-  hipStream_t stream = nullptr;
+  hipEvent_t run = nullptr;
+  bool busy = false;   // handed to the device -> host thread, not yet copied back
 };
 void free_chunk(ChunkBufs& b) {
   arena_free(b.arena);
-  if (b.stream) (void)hipStreamDestroy(b.stream);
+  if (b.run) (void)hipEventDestroy(b.run);
   b = ChunkBufs();
 }
-// Instances per chunk.  Default: the whole problem in one piece -- measured on this
-// platform, 2-D copies from PAGEABLE host arrays are staged synchronously by the runtime
-// and do not overlap anything (ncrms=65536: 42 ms in one piece vs 45 ms in 8 chunks, warm
-// pages; PCIe floor 38 ms), so chunking only pays as a bound on device memory.
-// MPDATA_HOST_CHUNK=<n> (rounded up to a multiple of 16) turns it on.
 int64_t host_chunk(int64_t ncrms) {
   const char* v = getenv("MPDATA_HOST_CHUNK");
-  if (!v) return ncrms;
-  int64_t c = atoll(v);
+  int64_t c = v ? atoll(v) : (ncrms + 7) / 8;
+  if (!v && c < 1024) c = 1024;
   if (c < 16) c = 16;
-  return (c + 15) / 16 * 16;
+  c = (c + 63) / 64 * 64;
+  return c < ncrms ? c : ncrms;
 }
+bool host_pin() {
+  const char* v = getenv("MPDATA_HOST_PIN");
+  return v && atoi(v) == 1;
+}
+struct Pinned {
+  void* p = nullptr;
+  bool mine = false;
+};
+Pinned pin_region(const void* p, size_t bytes) {
+  Pinned r;
+  r.p = const_cast<void*>(p);
+  const hipError_t e = hipHostRegister(r.p, bytes, hipHostRegisterDefault);
+  r.mine = e == hipSuccess;
+  if (e != hipSuccess) (void)hipGetLastError();  // already registered, or not registrable: use as is
+  return r;
+}
+struct OutJob {
+  int set;
+  int64_t c0, cw;
+};
 }  // namespace
 
 int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* f, const double* u,
@@ -738,36 +854,80 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
   int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
   if (!f || !u || !w || !rho || !rhow || !adz || !flux) return set_err(MPDATA_EINVAL, "null array pointer");
-  const int64_t C = host_chunk(ncrms) < ncrms ? host_chunk(ncrms) : ncrms;
+  const int64_t C = host_chunk(ncrms);
   const int64_t nchunks = (ncrms + C - 1) / C;
-  const int nsets = nchunks > 1 ? 2 : 1;
+  const int nsets = nchunks >= 3 ? 3 : (int)nchunks;
   const size_t nzm = (size_t)nz - 1;
   const size_t rows_f = (size_t)(nx + 6) * nzm * ntracers, rows_u = (size_t)(nx + 5) * nzm,
                rows_w = (size_t)(nx + 4) * nz, rows_k = nzm, rows_kz = (size_t)nz, rows_x = (size_t)nz * ntracers;
-  ChunkBufs set[2];
-  hipError_t e = hipSuccess;
+  const size_t hp = (size_t)ncrms * 8;  // host pitch: one row of all instances
+  Pinned pins[7];
+  if (host_pin()) {
+    const void* hptr[7] = {f, u, w, rho, rhow, adz, flux};
+    const size_t hrows[7] = {rows_f, rows_u, rows_w, rows_k, rows_kz, rows_k, rows_x};
+    for (int i = 0; i < 7; ++i) pins[i] = pin_region(hptr[i], hrows[i] * hp);
+  }
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  ChunkBufs set[3];
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking);
   for (int i = 0; i < nsets && e == hipSuccess; ++i) {
     ChunkBufs& b = set[i];
     const size_t nb[7] = {rows_f * C * 8, rows_u * C * 8, rows_w * C * 8, rows_k * C * 8, rows_kz * C * 8,
                           rows_k * C * 8, rows_x * C * 8};
-    if (e == hipSuccess) e = arena_alloc(b.arena, nb);
+    e = arena_alloc(b.arena, nb);
     if (e == hipSuccess) {
       b.f = (double*)b.arena.p[0]; b.u = (double*)b.arena.p[1]; b.w = (double*)b.arena.p[2];
       b.rho = (double*)b.arena.p[3]; b.rhow = (double*)b.arena.p[4]; b.adz = (double*)b.arena.p[5];
       b.flux = (double*)b.arena.p[6];
     }
-    if (e == hipSuccess) e = hipStreamCreate(&b.stream);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b.run, hipEventDisableTiming);
   }
-  const size_t hp = (size_t)ncrms * 8;  // host pitch: one row of all instances
+  // ---- the device -> host thread: takes finished chunks in order
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<OutJob> q;
+  bool done = false;
+  hipError_t e_out = hipSuccess;
+  std::thread out_thread([&]() {
+    (void)hipSetDevice(dev);
+    for (;;) {
+      OutJob j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done || !q.empty(); });
+        if (q.empty()) return;
+        j = q.front();
+        q.pop_front();
+      }
+      ChunkBufs& b = set[j.set];
+      const size_t dp = (size_t)j.cw * 8;
+      hipError_t x = hipStreamWaitEvent(s_out, b.run, 0);
+      if (x == hipSuccess) x = hipMemcpy2DAsync(f + j.c0, hp, b.f, dp, dp, rows_f, hipMemcpyDeviceToHost, s_out);
+      if (x == hipSuccess) x = hipMemcpy2DAsync(flux + j.c0, hp, b.flux, dp, dp, rows_x, hipMemcpyDeviceToHost, s_out);
+      if (x == hipSuccess) x = hipStreamSynchronize(s_out);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (x != hipSuccess && e_out == hipSuccess) e_out = x;
+        b.busy = false;   // the set is free again
+      }
+      cv.notify_all();
+    }
+  });
+  // ---- this thread: host -> device and the kernel of every chunk
   for (int64_t c = 0; c < nchunks && e == hipSuccess && rc == 0; ++c) {
     ChunkBufs& b = set[c % nsets];
     const int64_t c0 = c * C, cw = (c0 + C <= ncrms) ? C : ncrms - c0;
     const size_t dp = (size_t)cw * 8;  // device pitch: the chunk is its own problem, ld = cw
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !b.busy; });
+      if (e_out != hipSuccess) break;
+    }
     auto h2d = [&](double* d, const double* h, size_t rows) {
-      if (e == hipSuccess) e = hipMemcpy2DAsync(d, dp, h + c0, hp, dp, rows, hipMemcpyHostToDevice, b.stream);
-    };
-    auto d2h = [&](double* h, const double* d, size_t rows) {
-      if (e == hipSuccess) e = hipMemcpy2DAsync(h + c0, hp, d, dp, dp, rows, hipMemcpyDeviceToHost, b.stream);
+      if (e == hipSuccess) e = hipMemcpy2DAsync(d, dp, h + c0, hp, dp, rows, hipMemcpyHostToDevice, s_in);
     };
     h2d(b.f, f, rows_f);
     h2d(b.u, u, rows_u);
@@ -777,18 +937,33 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
     h2d(b.adz, adz, rows_k);
     h2d(b.flux, flux, rows_x);  // level nz is never written (reference :541,:624): carry it through
     if (e != hipSuccess) break;
-    rc = mpdata_advect_scalar2d_device(cw, nx, nz, ntracers, b.f, b.u, b.w, b.rho, b.rhow, b.adz, b.flux,
-                                       (void*)b.stream);
+    rc = mpdata_advect_scalar2d_device(cw, nx, nz, ntracers, b.f, b.u, b.w, b.rho, b.rhow, b.adz, b.flux, (void*)s_in);
     if (rc) break;
-    d2h(f, b.f, rows_f);
-    d2h(flux, b.flux, rows_x);
-  }
-  for (int i = 0; i < nsets; ++i)
-    if (set[i].stream) {
-      hipError_t e2 = hipStreamSynchronize(set[i].stream);
-      if (e == hipSuccess) e = e2;
+    e = hipEventRecord(b.run, s_in);
+    if (e != hipSuccess) break;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      b.busy = true;
+      q.push_back(OutJob{(int)(c % nsets), c0, cw});
     }
-  for (int i = 0; i < nsets; ++i) free_chunk(set[i]);
+    cv.notify_all();
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    done = true;
+  }
+  cv.notify_all();
+  out_thread.join();
+  if (e == hipSuccess) e = e_out;
+  for (hipStream_t st : {s_in, s_out})
+    if (st) {
+      const hipError_t e2 = hipStreamSynchronize(st);
+      if (e == hipSuccess) e = e2;
+      (void)hipStreamDestroy(st);
+    }
+  for (int i = 0; i < 3; ++i) free_chunk(set[i]);
+  for (int i = 0; i < 7; ++i)
+    if (pins[i].mine) (void)hipHostUnregister(pins[i].p);
   if (rc) return rc;
   if (e != hipSuccess) return hip_err(e, "mpdata_advect_scalar2d (streamed host call)");
   return 0;

@@ -19,18 +19,21 @@ module mpdata_grid
   integer(c_int)     :: nz = 58, nx = 32        !< reference :8-9
   integer(c_int)     :: nzm = 57                !< nz-1, reference :14
   integer(c_int)     :: ntracers = 1            !< this build's extension (tracer index slowest)
+  integer(c_int)     :: ngpus = 1               !< GPUs the ncrms axis is sharded over (this build's extension)
   real(rp), allocatable :: adz(:,:)             !< (nslices,nzm), reference :30
 contains
-  subroutine grid_set(ncrms_in, nx_in, nz_in, ntracers_in)
+  subroutine grid_set(ncrms_in, nx_in, nz_in, ntracers_in, ngpus_in)
     integer(c_int64_t), intent(in) :: ncrms_in
     integer, intent(in) :: nx_in, nz_in
-    integer, intent(in), optional :: ntracers_in
+    integer, intent(in), optional :: ntracers_in, ngpus_in
     nslices = ncrms_in
     nx = nx_in
     nz = nz_in
     nzm = nz_in - 1
     ntracers = 1
     if (present(ntracers_in)) ntracers = ntracers_in
+    ngpus = 1
+    if (present(ngpus_in)) ngpus = ngpus_in
     if (allocated(adz)) deallocate(adz)
     allocate(adz(nslices, nzm))
   end subroutine grid_set

@@ -16,7 +16,7 @@ module mpdata_hip_mod
   implicit none
   private
   public :: advect_scalar2D, advect_resident_begin, advect_resident_run, advect_resident_end
-  public :: mpdata_set_variant, mpdata_check
+  public :: mpdata_set_variant, mpdata_check, advect_transfer_stats
 
   ! the C entry points that carry reals exist per precision (include/mpdata_hip.h sections 1-3
   ! and 6); `make single=1` (-DMPDATA_SINGLE) binds the fp32 ones, rp = c_float
@@ -46,6 +46,21 @@ module mpdata_hip_mod
       integer(c_int64_t), value :: ncrms
       integer(c_int), value :: nx, nz, ntracers
       type(c_ptr) :: plan
+    end function
+    integer(c_int) function mpdata_plan_create_multi_c(ncrms, nx, nz, ntracers, ngpus, plan) &
+        bind(C, name="mpdata_plan_create_multi")
+      import :: c_int, c_int64_t, c_ptr
+      integer(c_int64_t), value :: ncrms
+      integer(c_int), value :: nx, nz, ntracers, ngpus
+      type(c_ptr) :: plan
+    end function
+    integer(c_int) function mpdata_plan_transfer_stats_c(plan, scatter_s, gather_s, sbytes, gbytes, transport) &
+        bind(C, name="mpdata_plan_transfer_stats")
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: plan
+      real(c_double) :: scatter_s, gather_s
+      integer(c_int64_t) :: sbytes, gbytes
+      integer(c_int) :: transport
     end function
     integer(c_int) function mpdata_plan_upload_c(plan, f, u, w, rho, rhow, adz, flux) bind(C, name=MPDATA_C_PLAN_UPLOAD)
       import :: c_int, c_ptr, rp
@@ -84,6 +99,9 @@ module mpdata_hip_mod
   end interface
 
   type(c_ptr), save :: resident_plan = c_null_ptr
+  ! scatter / gather record of the last multi-GPU transfer (advect_transfer_stats)
+  real(c_double), save :: last_scatter_s = 0, last_gather_s = 0
+  integer(c_int64_t), save :: last_scatter_bytes = 0, last_gather_bytes = 0
 
 contains
 
@@ -114,9 +132,51 @@ contains
     real(rp), intent(in   ) :: rho  (nslices, nzm)
     real(rp), intent(in   ) :: rhow (nslices, nz )
     real(rp), intent(inout) :: flux (nslices, nz, ntracers)   ! level nz is left as it came (reference :541,:624)
-    call mpdata_check(mpdata_advect_scalar2d_c(nslices, nx, nz, ntracers, f, u, w, rho, rhow, adz, flux), &
-                      'mpdata_advect_scalar2d')
+    type(c_ptr) :: plan
+    if (ngpus <= 1) then
+      call mpdata_check(mpdata_advect_scalar2d_c(nslices, nx, nz, ntracers, f, u, w, rho, rhow, adz, flux), &
+                        'mpdata_advect_scalar2d')
+    else
+      ! ncrms sharded over `ngpus` GPUs: scatter (RCCL over xGMI), one kernel per GPU, gather
+      call create_plan(plan)
+      call mpdata_check(mpdata_plan_upload_c(plan, f, u, w, rho, rhow, adz, flux), 'mpdata_plan_upload')
+      call mpdata_check(mpdata_plan_run_c(plan), 'mpdata_plan_run')
+      call mpdata_check(mpdata_plan_sync_c(plan), 'mpdata_plan_sync')
+      call mpdata_check(mpdata_plan_download_c(plan, f, flux), 'mpdata_plan_download')
+      call record_stats(plan)
+      call mpdata_check(mpdata_plan_destroy_c(plan), 'mpdata_plan_destroy')
+    end if
   end subroutine advect_scalar2D
+
+  subroutine create_plan(plan)
+    type(c_ptr), intent(out) :: plan
+    if (ngpus <= 1) then
+      call mpdata_check(mpdata_plan_create_c(nslices, nx, nz, ntracers, plan), 'mpdata_plan_create')
+    else
+#ifdef MPDATA_SINGLE
+      write(*,*) 'multi-GPU plans are fp64'
+      error stop 1
+#else
+      call mpdata_check(mpdata_plan_create_multi_c(nslices, nx, nz, ntracers, ngpus, plan), 'mpdata_plan_create_multi')
+#endif
+    end if
+  end subroutine create_plan
+
+  subroutine record_stats(plan)
+    type(c_ptr), intent(in) :: plan
+    integer(c_int) :: tr
+    if (ngpus <= 1) return
+    call mpdata_check(mpdata_plan_transfer_stats_c(plan, last_scatter_s, last_gather_s, last_scatter_bytes, &
+                                                   last_gather_bytes, tr), 'mpdata_plan_transfer_stats')
+  end subroutine record_stats
+
+  !> seconds and bytes per peer link of the last multi-GPU scatter (upload) / gather (download)
+  subroutine advect_transfer_stats(scatter_s, gather_s, scatter_bytes, gather_bytes)
+    real(c_double), intent(out) :: scatter_s, gather_s
+    integer(c_int64_t), intent(out) :: scatter_bytes, gather_bytes
+    scatter_s = last_scatter_s; gather_s = last_gather_s
+    scatter_bytes = last_scatter_bytes; gather_bytes = last_gather_bytes
+  end subroutine advect_transfer_stats
 
   !> Device-resident form = the reference's timed region (:105-110, :237-242):
   !! begin = `enter data` + `update device`; run = the kernels + `wait`;
@@ -124,7 +184,7 @@ contains
   subroutine advect_resident_begin(f, u, w, rho, rhow, flux)
     real(rp), intent(in) :: f(nslices, -2:nx+3, 1, nzm, ntracers), u(nslices, -1:nx+3, 1, nzm), w(nslices, -1:nx+2, 1, nz)
     real(rp), intent(in) :: rho(nslices, nzm), rhow(nslices, nz), flux(nslices, nz, ntracers)
-    call mpdata_check(mpdata_plan_create_c(nslices, nx, nz, ntracers, resident_plan), 'mpdata_plan_create')
+    call create_plan(resident_plan)
     call mpdata_check(mpdata_plan_upload_c(resident_plan, f, u, w, rho, rhow, adz, flux), 'mpdata_plan_upload')
   end subroutine advect_resident_begin
 
@@ -143,6 +203,7 @@ contains
     real(rp), intent(out) :: f(nslices, -2:nx+3, 1, nzm, ntracers)
     real(rp), intent(inout) :: flux(nslices, nz, ntracers)
     call mpdata_check(mpdata_plan_download_c(resident_plan, f, flux), 'mpdata_plan_download')
+    call record_stats(resident_plan)
     call mpdata_check(mpdata_plan_destroy_c(resident_plan), 'mpdata_plan_destroy')
     resident_plan = c_null_ptr
   end subroutine advect_resident_end

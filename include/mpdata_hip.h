@@ -42,6 +42,7 @@ extern "C" {
 #define MPDATA_EINVAL (-1)      /* bad sizes / null pointer */
 #define MPDATA_EUNSUPPORTED (-2) /* shape outside what the kernels cover */
 #define MPDATA_ESTATE (-3)      /* plan used before upload, etc. */
+#define MPDATA_ECOMM (-4)       /* RCCL error (multi-GPU plans) */
 
 /* kernel variants (mpdata_set_variant / MPDATA_VARIANT env): */
 #define MPDATA_VARIANT_EXACT 0  /* no FMA contraction, IEEE divide, reference
@@ -113,6 +114,29 @@ int mpdata_plan_set_stream(mpdata_plan* plan, void* stream);
 int mpdata_plan_layout(const mpdata_plan* plan);   /* MPDATA_LAYOUT_* */
 int mpdata_plan_device(const mpdata_plan* plan);   /* HIP device ordinal */
 int mpdata_set_plan_layout(int layout);            /* default for new plans; returns previous */
+
+/* ---- 3b. One problem on several GPUs of the node.  No statement of the routine couples two
+ * CRM instances (reference :505-637), so the ncrms axis is cut into `ngpus` contiguous blocks
+ * (mpdata_shard_range), each GPU runs a plan of its own on its block and there is NO data-path
+ * collective.  upload scatters the host arrays from GPU 0: H2D, pack kernel (a block is a
+ * strided slab: `sl` is the fastest axis), ncclSend / ncclRecv in one group -- RCCL over xGMI,
+ * one direct link per peer; download gathers f and flux the same way.  This replaces the
+ * reference's `!$acc update device / update host` (:107, :241-242).  One host thread drives all
+ * devices.  The handle is an ordinary plan: upload, run, run_tracers, sync, download,
+ * last_kernel_ms (slowest GPU) and destroy work on it; results are bitwise those of a
+ * single-GPU plan.  MPDATA_MULTI_XFER = rccl (default) | p2p (hipMemcpyPeerAsync) | direct
+ * (every GPU copies its slab from / to the host itself, no root). */
+int mpdata_plan_create_multi(int64_t ncrms, int nx, int nz, int ntracers, int ngpus, mpdata_plan** plan);
+int mpdata_plan_create_multi_devices(int64_t ncrms, int nx, int nz, int ntracers, int ngpus,
+                                     const int* devices, mpdata_plan** plan); /* explicit HIP ordinals */
+void mpdata_shard_range(int64_t ncrms, int ngpus, int g, int64_t* sl0, int64_t* nloc); /* block of GPU g */
+int mpdata_plan_ngpus(const mpdata_plan* plan);
+int mpdata_plan_shard(const mpdata_plan* plan, int g, int* device, int64_t* sl0, int64_t* nloc);
+/* wall seconds and bytes per peer link of the last upload (scatter) / download (gather);
+ * transport: 0 rccl, 1 p2p, 2 direct */
+int mpdata_plan_transfer_stats(const mpdata_plan* plan, double* scatter_s, double* gather_s,
+                               int64_t* scatter_bytes_per_peer, int64_t* gather_bytes_per_peer,
+                               int* transport);
 
 /* ---- 4. Synthetic inputs on the device (bench/tests; the reference's init,
  * :645-660, with a portable counter-based generator instead of the
