@@ -157,3 +157,71 @@ def test_layouts_agree_bitwise(M, oracle):
         else:
             assert oracle.rel_l1(f1, f2) < TOL_RELL1
             assert oracle.rel_l1(fl1[:, :-1], fl2[:, :-1]) < TOL_RELL1
+
+
+def _full_size_check(M, oracle, variant, ncrms, nx, nz, T, blocks, ngpus_devices=None):
+    """Device-generated inputs (the counter-based law is shard-invariant), a plan run, then
+    (i) sampled blocks of instances against the oracle on regenerated inputs -- instances are
+    independent (reference :505-637) -- for EVERY tracer, (ii) the size-independent output
+    contract on the whole arrays of every tracer."""
+    import torch
+    M.set_variant(variant)
+    sh = M.shapes(ncrms, nx, nz, 1)
+    d = {k: torch.empty(s, dtype=torch.float64, device="cuda:0") for k, s in sh.items()}
+    for k in ("u", "w", "rho", "rhow", "adz", "flux"):
+        M.fill_synthetic(d[k], k, 100, oracle.DIST_CONDITIONED)
+    p = M.Plan(ncrms, nx, nz, T)
+    assert p.layout == M.LAYOUT_WAVEMAJOR
+    p.import_device(None, d["u"], d["w"], d["rho"], d["rhow"], d["adz"], None)
+    for t in range(T):
+        M.fill_synthetic(d["f"], "f", 100 + t, oracle.DIST_CONDITIONED)
+        p.import_device(d["f"], flux=d["flux"], first_tracer=t)
+    p.run()
+    p.sync()
+    flux_in_top = d["flux"][nz - 1].clone()
+    fo, flo = torch.empty_like(d["f"]), torch.empty_like(d["flux"])
+    shared = {}
+    for t in range(T):
+        p.export_device(fo, flo, first_tracer=t)
+        M.fill_synthetic(d["f"], "f", 100 + t, oracle.DIST_CONDITIONED)   # the tracer's input again
+        torch.cuda.synchronize()
+        # contract: columns -2 / nx+3 and flux level nz untouched, interior >= 0, all finite
+        assert torch.equal(fo[:, 0, :], d["f"][:, 0, :]) and torch.equal(fo[:, nx + 5, :], d["f"][:, nx + 5, :])
+        assert torch.equal(flo[nz - 1], flux_in_top)
+        assert float(fo[:, 3:3 + nx, :].min()) >= 0.0
+        assert bool(torch.isfinite(fo).all()) and bool(torch.isfinite(flo).all())
+        for s0, n in blocks:
+            if (s0, n) not in shared:
+                shared[(s0, n)] = oracle.make_inputs(n, nx, nz, seed=100, dist=oracle.DIST_CONDITIONED,
+                                                     ncrms_global=ncrms, sl0=s0)
+            inp = dict(shared[(s0, n)])
+            inp["f"] = oracle.fill_array("f", (n, nx + 6, nz - 1), 100 + t, oracle.DIST_CONDITIONED,
+                                         ncrms_global=ncrms, sl0=s0)
+            f_ref, flux_ref = oracle.advect(inp)
+            f = to_host(fo[..., s0:s0 + n])
+            flux = to_host(flo[..., s0:s0 + n])
+            if variant == M.VARIANT_EXACT:
+                assert np.array_equal(f, f_ref) and flux_close(flux, flux_ref), (t, s0)
+            else:
+                assert max_abs(f, f_ref) < TOL_ABS and max_abs(flux, flux_ref) < TOL_ABS, (t, s0)
+    p.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["exact", "fast"])
+def test_full_size_config3_plan_sampled_against_oracle(M, oracle, variant):
+    """BASELINE.json configs[2]: ncrms=65536 nx=32 nz=28 fp64, 1 tracer, through the plan API."""
+    _full_size_check(M, oracle, variant, 65536, 32, 28, 1, ((0, 64), (30000 + 7, 50), (65536 - 33, 33)))
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["exact", "fast"])
+def test_full_size_config4_sampled_against_oracle(M, oracle, variant):
+    """BASELINE.json configs[3] (= the per-GPU problem of configs[4]): ncrms=65536, 25 tracers
+    batched per CRM instance (13.45 GB of f), every tracer checked."""
+    _full_size_check(M, oracle, variant, 65536, 32, 28, 25, ((0, 40), (41234 + 5, 31), (65536 - 17, 17)))
+
+
+def test_plan_arrays_larger_than_4GiB(M, oracle):
+    """ncrms = 600000 (f, u, w 4.8-4.9 GB each; the wave-major kernel addresses a tile with 32-bit
+    offsets relative to per-wave descriptor bases, so array size does not matter)."""
+    _full_size_check(M, oracle, M.VARIANT_EXACT, 600000, 32, 28, 1,
+                     ((0, 40), (123456 + 3, 37), (299990, 50), (600000 - 21, 21)))

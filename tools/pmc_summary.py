@@ -1,13 +1,23 @@
 """Aggregate gpurun_out/prof_<tag>/ (written by tools/profile_round.sh) into profiles/:
-<tag>_kernel_stats.csv, <tag>_domain_stats.csv, <tag>_pmc_summary.json, hbm_traffic.json."""
+<tag>_kernel_stats.csv, <tag>_domain_stats.csv, <tag>_t25_kernel_stats.csv, <tag>_pmc_summary.json,
+hbm_traffic.json (the per-launch HBM bytes bench.py quotes as `roofline.traffic`, with their source)."""
 import csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
-KERNEL = "mpdata_advect_xmarch_kernel"
 NCRMS, NX, NZ = 65536, 32, 28
+# kernel-name fragments: wave-major kernel, column-granular fetch (1 tracer) / pair-granular
+# (tracer batches); x-march kernel (reference layout)
+K_WM1, K_WMT, K_XM = "mpdata_advect_wm_kernel<double,32,4,true>", "mpdata_advect_wm_kernel<double,32,4,false>", "mpdata_advect_xmarch_kernel"
+
+
+def is_k(kernel, name):
+    """kernel-name match on the demangled name, blanks ignored (mangled fragments also accepted)"""
+    n = name.replace(" ", "")
+    alt = {K_WM1: "wm_kernelIdLi32ELi4ELb1", K_WMT: "wm_kernelIdLi32ELi4ELb0"}.get(kernel, kernel)
+    return kernel in n or alt in n
 
 
 def one(pattern):
@@ -17,74 +27,125 @@ def one(pattern):
     return hits[0]
 
 
-def counters(passname):
-    """{counter: (sum over dispatches of the kernel, number of dispatches)}"""
+def have(pattern):
+    return len(glob.glob(os.path.join(src, pattern), recursive=True)) == 1
+
+
+def counters(passname, kernel):
+    """{counter: mean over the dispatches of `kernel`} (a counter's rows of one dispatch are summed)"""
     acc, disp = {}, {}
     with open(one(f"{passname}/**/*_counter_collection.csv")) as fh:
         for row in csv.DictReader(fh):
-            if KERNEL not in row["Kernel_Name"]:
+            if not is_k(kernel, row["Kernel_Name"]):
                 continue
             c = row["Counter_Name"]
             acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
             disp.setdefault(c, set()).add(row["Dispatch_Id"])
-    return {c: (v, len(disp[c])) for c, v in acc.items()}
+    return {c: v / len(disp[c]) for c, v in acc.items()}
 
 
-shutil.copy(one("kt/**/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+def trace(passname, kernel, out):
+    shutil.copy(one(f"{passname}/**/*_kernel_stats.csv"), os.path.join(dst, out))
+    with open(os.path.join(dst, out)) as fh:
+        for row in csv.DictReader(fh):
+            if is_k(kernel, row["Name"]):
+                return {"name": row["Name"], "avg_ns": float(row["AverageNs"]), "calls": int(row["Calls"]),
+                        "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"])}
+    return None
+
+
+def alg_bytes(t):
+    return NCRMS * 8 * (NZ - 1) * (t * (2 * NX + 11) + 2 * NX + 12)
+
+
+def hbm(fetch_pass, write_pass, kernel):
+    # gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section):
+    # FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports half of wide coalesced reads.
+    rd = counters(fetch_pass, kernel)["FETCH_SIZE"] * 1024 * 2
+    wr = counters(write_pass, kernel)["WRITE_SIZE"] * 1024
+    return rd, wr
+
+
+summary = {"commands": "tools/profile_round.sh: rocprofv3 --kernel-trace --stats and separate --pmc passes "
+                       "(FETCH_SIZE | WRITE_SIZE | TCC_* | SQ_*) of bench.py",
+           "correction": "FETCH_SIZE KiB x 2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE KiB exact; "
+                         "MI355X_MICROARCH.md section HBM"}
+traffic = {}
+
+# ---- headline: 1 tracer, plan API, wave-major layout ------------------------------------------
+kt = trace("kt", K_WM1, f"{tag}_kernel_stats.csv")
 shutil.copy(one("kt/**/*_domain_stats.csv"), os.path.join(dst, f"{tag}_domain_stats.csv"))
-avg_ns = None
-with open(os.path.join(dst, f"{tag}_kernel_stats.csv")) as fh:
-    for row in csv.DictReader(fh):
-        if KERNEL in row["Name"]:
-            avg_ns = float(row["AverageNs"]); calls = int(row["Calls"]); name = row["Name"]
+rd, wr = hbm("fetch", "write", K_WM1)
+sq = counters("sq", K_WM1)
+waves = sq["SQ_WAVES"]
+summary["t1_wavemajor"] = {
+    "config": f"ncrms={NCRMS} nx={NX} nz={NZ}, 1 tracer, FAST variant, plan API (wave-major layout)",
+    "kernel_trace": kt, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+    "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg_bytes(1),
+    "ratio_traffic_over_algorithmic": (rd + wr) / alg_bytes(1),
+    "algorithmic_GBs_at_kernel_trace_avg": alg_bytes(1) / kt["avg_ns"],
+    "frac_of_8TBs": alg_bytes(1) / kt["avg_ns"] / 8000.0,
+    "sq_per_wave": {c: v / waves for c, v in sq.items() if c != "SQ_WAVES"}, "waves": waves,
+    "valu_instructions_per_wave": sq["SQ_INSTS_VALU"] / waves}
+traffic[f"fast_ncrms{NCRMS}_nx{NX}_nz{NZ}_t1_wm"] = {"hbm_bytes_per_launch": rd + wr,
+                                                     "source": f"profiles/{tag}_pmc_summary.json t1_wavemajor"}
+traffic[f"exact_ncrms{NCRMS}_nx{NX}_nz{NZ}_t1_wm"] = {"hbm_bytes_per_launch": rd + wr,
+                                                      "source": "same loads / stores in both variants"}
 
-fetch, write, sq = counters("fetch"), counters("write"), counters("sq")
-nd = fetch["FETCH_SIZE"][1]
-# gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section):
-# FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports half of wide coalesced reads.
-rd = fetch["FETCH_SIZE"][0] / nd * 1024 * 2
-wr = write["WRITE_SIZE"][0] / write["WRITE_SIZE"][1] * 1024
-alg = 8 * (NZ - 1) * (4 * NX + 23) * NCRMS
-nsteps = NX + 6
-waves = sq["SQ_WAVES"][0] / sq["SQ_WAVES"][1]
-per = {c: v / n / (waves * nsteps) for c, (v, n) in sq.items() if c != "SQ_WAVES"}
-summary = {
-    "kernel": name, "config": f"ncrms={NCRMS} nx={NX} nz={NZ}, 1 tracer, FAST variant",
-    "commands": "tools/profile_round.sh (rocprofv3 --kernel-trace --stats; separate --pmc passes: "
-                "FETCH_SIZE | WRITE_SIZE GRBM_GUI_ACTIVE | SQ_*)",
-    "kernel_trace_avg_ns": avg_ns, "kernel_trace_calls": calls,
-    "correction": "FETCH_SIZE KiB x2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE KiB "
-                  "exact; MI355X_MICROARCH.md section HBM",
-    "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
-    "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg,
-    "ratio_traffic_over_algorithmic": (rd + wr) / alg,
-    "sq_per_wave_step_quad_cycles": per,
-    "valu_busy_fraction": per["SQ_ACTIVE_INST_VALU"] * 4 / per["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in per else None,
-    "note": f"SQ_* per wave and column step ({int(waves)} waves x {nsteps} steps); SQ_ACTIVE_*/WAVE_CYCLES in "
-            "quad-cycles; 4 waves share a SIMD, so VALU busy per SIMD = 4 x ACTIVE_INST_VALU / WAVE_CYCLES",
-}
+# ---- 25 tracers ----------------------------------------------------------------------------------
+if have("t25_fetch/**/*_counter_collection.csv"):
+    kt25 = trace("t25_kt", K_WMT, f"{tag}_t25_kernel_stats.csv")
+    rd, wr = hbm("t25_fetch", "t25_write", K_WMT)
+    tcc = counters("t25_tcc", K_WMT)
+    sq = counters("t25_sq", K_WMT)
+    waves = sq["SQ_WAVES"]
+    vpw = sq["SQ_INSTS_VALU"] / waves
+    valu_peak = 33.0e12 / 64.0   # wave-instructions / s, tools/valu_rate.hip
+    summary["t25_wavemajor"] = {
+        "config": f"ncrms={NCRMS} nx={NX} nz={NZ}, 25 tracers, FAST variant, plan API (wave-major layout)",
+        "kernel_trace": kt25, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+        "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg_bytes(25),
+        "ratio_traffic_over_algorithmic": (rd + wr) / alg_bytes(25),
+        "algorithmic_GBs_at_kernel_trace_avg": alg_bytes(25) / kt25["avg_ns"],
+        "hbm_frac_of_8TBs": alg_bytes(25) / kt25["avg_ns"] / 8000.0,
+        "l2_hit_rate": tcc["TCC_HIT_sum"] / (tcc["TCC_HIT_sum"] + tcc["TCC_MISS_sum"]),
+        "waves": waves, "valu_instructions_per_wave": vpw,
+        "valu_time_at_measured_peak_ms": waves * vpw / valu_peak * 1e3,
+        "valu_frac": waves * vpw / valu_peak / (kt25["avg_ns"] * 1e-9),
+        "valu_note": "VALU wave-instructions per launch / (33e12 lane-ops/s / 64, tools/valu_rate.hip) / kernel time",
+        "sq_per_wave": {c: v / waves for c, v in sq.items() if c != "SQ_WAVES"}}
+    for v in ("fast", "exact"):
+        traffic[f"{v}_ncrms{NCRMS}_nx{NX}_nz{NZ}_t25_wm"] = {"hbm_bytes_per_launch": rd + wr,
+                                                            "source": f"profiles/{tag}_pmc_summary.json t25_wavemajor"}
+
+# ---- reference-layout device call (x-march kernel) --------------------------------------------
+if have("ref_fetch/**/*_counter_collection.csv"):
+    rd, wr = hbm("ref_fetch", "ref_write", K_XM)
+    summary["t1_reference_layout"] = {
+        "config": f"ncrms={NCRMS} nx={NX} nz={NZ}, 1 tracer, FAST variant, mpdata_advect_scalar2d_device (x-march kernel)",
+        "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg_bytes(1),
+        "ratio_traffic_over_algorithmic": (rd + wr) / alg_bytes(1)}
+    for v in ("fast", "exact"):
+        traffic[f"{v}_ncrms{NCRMS}_nx{NX}_nz{NZ}_t1"] = {"hbm_bytes_per_launch": rd + wr,
+                                                         "source": f"profiles/{tag}_pmc_summary.json t1_reference_layout"}
+
 with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
 with open(os.path.join(dst, "hbm_traffic.json"), "w") as fh:
-    key = f"ncrms{NCRMS}_nx{NX}_nz{NZ}_t1"
-    json.dump({"fast_" + key: {"hbm_bytes_per_launch": rd + wr, "source": f"profiles/{tag}_pmc_summary.json"},
-               "exact_" + key: {"hbm_bytes_per_launch": rd + wr,
-                                "source": f"profiles/{tag}_pmc_summary.json (same loads/stores in both variants)"}},
-              fh, indent=1)
+    json.dump(traffic, fh, indent=1)
 print(json.dumps(summary, indent=1))
 
 # ---- second kernel: biharmonic_wk_scalar (tools/bwk_bench.py: nelemd=5400, both variants) ----
-if glob.glob(os.path.join(src, "bwk_kt", "**", "*_kernel_stats.csv"), recursive=True):
+if have("bwk_kt/**/*_kernel_stats.csv"):
     KERNEL = "bwk_kernel"
     shutil.copy(one("bwk_kt/**/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_bwk_kernel_stats.csv"))
     rows = {}
     with open(os.path.join(dst, f"{tag}_bwk_kernel_stats.csv")) as fh:
         for row in csv.DictReader(fh):
-            if KERNEL in row["Name"]:
+            if is_k(KERNEL, row["Name"]):
                 rows[row["Name"]] = {"avg_ns": float(row["AverageNs"]), "calls": int(row["Calls"])}
-    bf, bw = counters("bwk_fetch"), counters("bwk_write")
-    brd = bf["FETCH_SIZE"][0] / bf["FETCH_SIZE"][1] * 1024 * 2
-    bwr = bw["WRITE_SIZE"][0] / bw["WRITE_SIZE"][1] * 1024
+    brd = counters("bwk_fetch", KERNEL)["FETCH_SIZE"] * 1024 * 2
+    bwr = counters("bwk_write", KERNEL)["WRITE_SIZE"] * 1024
     balg = 2 * 8 * 16 * 72 * 40 * 5400 + 8 * (144 * 5400 + 16)
     bsum = {"kernel": "bwk_kernel (biharmonic_wk_scalar), nelemd=5400 nlev=72 qsize=40", "kernel_trace": rows,
             "hbm_read_bytes_per_launch": brd, "hbm_write_bytes_per_launch": bwr,

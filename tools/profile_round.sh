@@ -1,21 +1,34 @@
 #!/bin/bash
-# Round profile: kernel-trace stats + three separate PMC passes of the headline bench, then the
-# summaries the judge reads are written into profiles/ by tools/pmc_summary.py.
-#   usage (on the GPU box):  bash tools/profile_round.sh r01
+# Round profile: kernel-trace stats + separate PMC passes of the headline bench (1 tracer, plan
+# API, wave-major layout) and of the 25-tracer batch, then tools/pmc_summary.py writes the
+# summaries the judge reads into profiles/.
+#   usage (on the GPU box):  bash tools/profile_round.sh r02
 # rocprofv3 rules of this pool: the program itself after `--`; --pmc never together with
 # --kernel-trace/--stats; one counter group per pass.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline --no-batched --no-fp32 --no-bwk"
-S="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batched --no-fp32 --no-bwk"
+X="--no-cpu-baseline --no-fp32 --no-bwk --no-reflayout"
+B="python3 $ROOT/bench.py $X --no-batched"
+S="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 $X --no-batched"
+T="python3 $ROOT/bench.py --steps 2 --warmup 1 --prewarm-ms 0 --batched-steps 2 $X"
+R="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --layout reference --no-cpu-baseline --no-fp32 --no-bwk --no-batched"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o run -- $B > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- $S > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/write -o run -- $S > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/sq -o run -- $S > $OUT/sq.log 2>&1
+# 25 tracers: kernel trace, HBM traffic, L2 hit rate, SQ
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t25_kt -o run -- python3 $ROOT/bench.py --steps 20 --warmup 2 $X > $OUT/t25_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/t25_fetch -o run -- $T > $OUT/t25_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/t25_write -o run -- $T > $OUT/t25_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/t25_tcc -o run -- $T > $OUT/t25_tcc.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/t25_sq -o run -- $T > $OUT/t25_sq.log 2>&1
+# reference-layout device call (x-march kernel): HBM traffic
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/ref_fetch -o run -- $R > $OUT/ref_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/ref_write -o run -- $R > $OUT/ref_write.log 2>&1
 # second kernel (biharmonic_wk_scalar, nelemd=5400): kernel trace + HBM traffic
 W="python3 $ROOT/tools/bwk_bench.py --child -"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bwk_kt -o run -- $W > $OUT/bwk_kt.log 2>&1
