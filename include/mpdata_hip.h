@@ -45,13 +45,24 @@ extern "C" {
 #define MPDATA_ECOMM (-4)       /* RCCL error (multi-GPU plans) */
 
 /* kernel variants (mpdata_set_variant / MPDATA_VARIANT env): */
-#define MPDATA_VARIANT_EXACT 0  /* no FMA contraction, IEEE divide, reference
-                                   summation order: bit-identical to the
-                                   reference CPU routine built with
-                                   -ffp-contract=off */
-#define MPDATA_VARIANT_FAST 1   /* FMA contraction allowed; differs from the
-                                   above by rounding only (< 1e-12 abs on
-                                   conditioned inputs) */
+#define MPDATA_VARIANT_EXACT 0  /* no FMA contraction, IEEE divide, the reference's
+                                   expression order: f (every element, halos
+                                   included) is BIT-IDENTICAL to the reference
+                                   CPU routine built with -ffp-contract=off.
+                                   flux(:,1:nzm) is the sum of the reference's
+                                   terms in another order (sum of upwind terms +
+                                   sum of limited terms, each in the reference's
+                                   i order, instead of the limited terms added
+                                   one by one onto the finished upwind sum, :545,
+                                   :624): equal to <= 1e-13 relative, not
+                                   bitwise.  (Bit-exact flux: the k-marching
+                                   kernels, mpdata_set_tile(0..4), reference-
+                                   layout calls only.) */
+#define MPDATA_VARIANT_FAST 1   /* FMA contraction allowed, Newton reciprocal in
+                                   the limiter: differs from the above by
+                                   rounding only (< 1e-12 abs on conditioned
+                                   inputs, < 1e-14 relative L1 on the reference's
+                                   own input law) */
 
 /* ---- 1. Drop-in call: host arrays, synchronous, transfers included. -------
  * Replaces `call advect_scalar2D_openacc_N(f,u,w,rho,rhow,flux)` (reference
