@@ -185,44 +185,60 @@ def bench_bwk(torch, dev, steps, warmup, with_cpu):
 
 def bench_nlk(torch, dev, steps, warmup, with_cpu):
     """Side measurement of the third kernel: the MPAS-Ocean high-order flux loop
-    nest at the reference's namelist size (nested_loops/nested.nml: 25600 edges, 2800 cells,
-    100 levels, 10 cells per edge), FAST variant, device-resident."""
+    nest, FAST variant, device-resident.  Two sizes: the reference's namelist
+    (nested_loops/nested.nml: 25600 edges, 2800 cells, 100 levels, 10 cells per edge: a 37-us launch
+    on a 69-MB working set, i.e. launch / L2-gather territory -- reported WITHOUT an HBM fraction)
+    and a mesh 32 x larger (819200 edges, 89600 cells: 2.2 GB of compulsory traffic per call, well
+    past the 256-MB Infinity Cache), where the HBM roofline is the right yardstick."""
     import numpy as np
     import codesign_kernels_amd.nlk as K
-    nE, nC, nV, nA = 25600, 2800, 100, 10
     K.set_variant(K.VARIANT_FAST)
-    g = torch.Generator(device=dev).manual_seed(3)
-    rnd = lambda *shape: torch.rand(shape, dtype=torch.float64, device=dev, generator=g)
-    d = {"nAdvCellsForEdge": torch.full((nE,), nA, dtype=torch.int32, device=dev),
-         "advCellsForEdge": torch.randint(1, nC + 1, (nE, nA), dtype=torch.int32, device=dev, generator=g),
-         "minLevelCell": torch.ones((nC,), dtype=torch.int32, device=dev),
-         "maxLevelCell": torch.clamp((rnd(nC) * nV * 2).round().to(torch.int32), 3, nV),
-         "tracerCur": 15.0 * rnd(nC, nV), "normalThicknessFlux": 15.0 * (0.5 - rnd(nE, nV)),
-         "advMaskHighOrder": torch.ones((nE, nV), dtype=torch.float64, device=dev),
-         "advCoefs": 20.0 * rnd(nE, nA), "advCoefs3rd": 21.0 * rnd(nE, nA)}
-    out = torch.zeros((nE, nV), dtype=torch.float64, device=dev)
     coef = float(np.float32(2.14))
-    for _ in range(warmup):
-        K.high_order_flux(d, nV, coef, out)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
-        K.high_order_flux(d, nV, coef, out)
-    e1.record()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kms = e0.elapsed_time(e1) / steps
-    ab = K.algorithmic_bytes(nE, nC, nV, nV, nA)
+
+    def one(nE, nC, nV, nA, steps, warmup):
+        g = torch.Generator(device=dev).manual_seed(3)
+        rnd = lambda *shape: torch.rand(shape, dtype=torch.float64, device=dev, generator=g)
+        d = {"nAdvCellsForEdge": torch.full((nE,), nA, dtype=torch.int32, device=dev),
+             "advCellsForEdge": torch.randint(1, nC + 1, (nE, nA), dtype=torch.int32, device=dev, generator=g),
+             "minLevelCell": torch.ones((nC,), dtype=torch.int32, device=dev),
+             "maxLevelCell": torch.clamp((rnd(nC) * nV * 2).round().to(torch.int32), 3, nV),
+             "tracerCur": 15.0 * rnd(nC, nV), "normalThicknessFlux": 15.0 * (0.5 - rnd(nE, nV)),
+             "advMaskHighOrder": torch.ones((nE, nV), dtype=torch.float64, device=dev),
+             "advCoefs": 20.0 * rnd(nE, nA), "advCoefs3rd": 21.0 * rnd(nE, nA)}
+        out = torch.zeros((nE, nV), dtype=torch.float64, device=dev)
+        for _ in range(warmup):
+            K.high_order_flux(d, nV, coef, out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            K.high_order_flux(d, nV, coef, out)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kms = e0.elapsed_time(e1) / steps
+        return dt, kms, K.algorithmic_bytes(nE, nC, nV, nV, nA)
+
+    nE, nC, nV, nA = 25600, 2800, 100, 10
+    dt, kms, ab = one(nE, nC, nV, nA, steps, warmup)
     res = {"workload": f"nested_loops/nested.F90 high-order flux loop nest: nEdges={nE} nCells={nC} "
-                       f"nVertLevels={nV} nAdv={nA} fp64, device-resident",
+                       f"nVertLevels={nV} nAdv={nA} fp64, device-resident (the reference's namelist size)",
            "value": nE * nV * steps / dt, "unit": "edge-level fluxes/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
-           "roofline": {"bound": "hbm", "achieved": ab / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
-                        "kernel_ms_avg": kms,
-                        "note": "62 MB per call: the working set fits the 256-MB Infinity Cache and the call is "
-                                "short; launch-latency territory, not an HBM-bound measurement"}}
+           "kernel_ms_avg": kms, "algorithmic_bytes_per_launch": ab,
+           "note": "69 MB per call, inside the Infinity Cache, 37 us per launch: not an HBM-bound measurement, no "
+                   "roofline fraction is claimed for this size"}
+    big = 32
+    s2 = max(5, steps // 5)
+    dt2, kms2, ab2 = one(nE * big, nC * big, nV, nA, s2, 3)
+    res["large_mesh"] = {
+        "workload": f"the same nest on a mesh {big} x larger: nEdges={nE * big} nCells={nC * big} nVertLevels={nV} nAdv={nA}",
+        "value": nE * big * nV * s2 / dt2, "unit": "edge-level fluxes/s", "steps": s2, "ms_per_step": dt2 / s2 * 1e3,
+        "roofline": {"bound": "hbm", "achieved": ab2 / (kms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ab2 / (kms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab2,
+                     "kernel_ms_avg": kms2,
+                     "note": "compulsory bytes only; the tracerCur columns the gather re-reads (about 3 x the "
+                             "compulsory traffic, from L2 / Infinity Cache) are not counted"}}
     if with_cpu:
         from oracle import nlk as N
         N.build_lib()
@@ -445,11 +461,16 @@ def main():
                                           "(like the reference's `!$acc update device`, :107)"},
         }
         try:
-            c = copy_ceiling(torch, dev)
-            result["roofline"]["measured_copy_GBs"] = c
-            result["roofline"]["frac_of_measured_copy"] = result["roofline"]["achieved"] / c
+            result["roofline"]["measured_copy_GBs"] = copy_ceiling(torch, dev)
         except Exception:
             result["roofline"]["measured_copy_GBs"] = None
+        try:   # the routine's own mix (3 reads : 1 write, in place) as a linear aligned stream
+            plain = M.stream_ceiling(nontemporal=False)
+            nt = M.stream_ceiling(nontemporal=True)
+            result["roofline"]["measured_stream_3r1w_GBs"] = {"plain": plain, "nontemporal": nt}
+            result["roofline"]["frac_of_measured_ceiling"] = result["roofline"]["achieved"] / max(plain, nt)
+        except Exception:
+            result["roofline"]["measured_stream_3r1w_GBs"] = None
 
     # ---- BASELINE configs[3] / [4]: 25 tracers per instance, every rank ---------------------
     if not args.no_batched and ntr == 1:

@@ -129,6 +129,8 @@ def lib():
         L.mpdata_device_count.restype = ci
         L.mpdata_algorithmic_bytes.restype = i64
         L.mpdata_algorithmic_bytes.argtypes = [i64, ci, ci, ci]
+        L.mpdata_diag_stream_3r1w.restype = ci
+        L.mpdata_diag_stream_3r1w.argtypes = [i64, ci, ci, ctypes.POINTER(ctypes.c_double)]
         L.mpdata_last_error.restype = ctypes.c_char_p
         L.mpdata_version.restype = ctypes.c_char_p
         _lib = L
@@ -162,6 +164,13 @@ def shard_range(ncrms, ngpus, g):
     a, b = ctypes.c_int64(), ctypes.c_int64()
     lib().mpdata_shard_range(int(ncrms), int(ngpus), int(g), ctypes.byref(a), ctypes.byref(b))
     return a.value, b.value
+
+
+def stream_ceiling(bytes_per_array=538 * 2**20, nontemporal=True, iters=40):
+    """GB/s of a linear 3-read-1-write stream on the current device (mpdata_diag_stream_3r1w)."""
+    g = ctypes.c_double()
+    _check(lib().mpdata_diag_stream_3r1w(int(bytes_per_array), int(bool(nontemporal)), int(iters), ctypes.byref(g)))
+    return g.value
 
 
 def device_count():

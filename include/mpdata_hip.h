@@ -218,6 +218,9 @@ int mpdata_set_tile(int tile);            /* kernel tiling id; -
 int mpdata_set_debug_buffer(void* dev_ptr); /* diagnostic builds only: clock-stamp buffer */
 int mpdata_device_count(void);
 int64_t mpdata_algorithmic_bytes(int64_t ncrms, int nx, int nz, int ntracers);
+/* Diagnostic: GB/s this GPU sustains for the routine's traffic mix (3 arrays read, 1 written in
+ * place) as a linear, aligned, 16-byte-per-lane stream; nontemporal = 1: streaming loads/stores. */
+int mpdata_diag_stream_3r1w(int64_t bytes_per_array, int nontemporal, int iters, double* gbs);
 const char* mpdata_last_error(void);
 const char* mpdata_version(void);
 

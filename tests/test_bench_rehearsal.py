@@ -14,11 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_two_rank_bench_prints_one_whole_job_line():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a port the OS hands out
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MPDATA_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--ncrms-per-gpu", "4096",
-           "--no-batched", "--no-fp32", "--no-bwk", "--no-cpu-baseline"]
+           "--batched-tracers", "3", "--batched-steps", "2", "--no-fp32", "--no-bwk", "--no-cpu-baseline"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -27,3 +31,8 @@ def test_two_rank_bench_prints_one_whole_job_line():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["config"]["ncrms_global"] == 2 * 4096
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    # configs[4] block (tracer batch on every rank) and the reference-layout side block ran too
+    tb = d["tracer_batched"]
+    assert tb["n_gpus"] == 2 and tb["steps"] == 2 and tb["value"] > 0 and "configs[4]" in tb["workload"]
+    assert d["reference_layout_device_call"]["value"] > 0
+    assert "scatter_gather" in d      # (gloo cannot move device tensors: an error entry in the rehearsal)

@@ -51,13 +51,21 @@ def _worker(rank, world, port, ncrms, nx, nz, q):
         dist.destroy_process_group()
 
 
+def _free_port():
+    """a port the OS hands out (bind to 0), instead of one derived from the pid"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 @pytest.mark.parametrize("ncrms", [10, 7])
 def test_scatter_advect_gather_world2(ncrms):
     from oracle import oracle as O
     O.build_lib()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + ncrms
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, ncrms, 8, 6, q)) for r in range(2)]
     for p in procs:
         p.start()
