@@ -118,6 +118,9 @@ __device__ __forceinline__ double recip_nr(double d) {
   double r = __builtin_amdgcn_rcp(d);
   double e = __builtin_fma(-d, r, 1.0);
   r = __builtin_fma(r, e, r);
+#ifdef MPDATA_RECIP_NR1  // experiment: one Newton step
+  return r;
+#endif
   e = __builtin_fma(-d, r, 1.0);
   return __builtin_fma(r, e, r);
 }
@@ -500,8 +503,11 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
     // old), out tile of column q-4 written: then everyone's are, after the barrier
     STAMP();
     static_assert(T::NSLOT == 4 && (T::VM_PER_STEP == 7 || T::VM_PER_STEP == 4), "the counted waits below assume them");
-    if constexpr (T::VM_PER_STEP == 7) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    // (only the DMA instructions of the two newer columns may still be outstanding: loads return in
+    //  issue order, but a row store may be acknowledged before an older load has landed, so the
+    //  stores issued in between must not be counted -- vmcnt(14) / vmcnt(8) would be a race)
+    if constexpr (T::VM_PER_STEP == 7) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     STAMP();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");

@@ -15,14 +15,22 @@
 //     rho, adz, rhow(1:nzm) :  [tile][3][s][k]         flux :  [tracer][tile][s][k]
 //
 // with tile = SLP adjacent instances = what ONE WAVE works on.  A column of a tile ("chunk",
-// SLP*nzm elements) is contiguous, consecutive columns are adjacent: every wave reads three
-// linear streams and writes one.  Consequences:
+// SLP*nzm elements, 432 bytes at nz = 28) is split into its whole 128-byte lines (the "main" part,
+// 384 bytes) and the rest (48 bytes); a tile stores the main parts of all its columns first, then
+// the remainders:   [tile][ main: column][..]  [ remainder: column][..] , tiles at an odd number of
+// 128-byte lines.  Every line of a main part is then touched by exactly ONE fetch and ONE store
+// instruction, which is what makes non-temporal (streaming) accesses pay: +20 % in the bare data
+// movement (tools/wave_stream.hip: 6.4 TB/s against 5.3 TB/s for contiguous 432-byte chunks;
+// with a line shared by two instructions the streaming hint evicts it in between).  The
+// remainders -- one line serves 2.7 columns -- are fetched and stored with the default policy.
+// Every wave reads three linear streams (+ three small ones) and writes one.  Consequences:
 //   * waves are independent: no workgroup barrier, no transpose (the LDS image of a chunk IS
 //     the lane order), no LDS tile for the write-back (a finished column is stored from
 //     registers, SLP*nzm*8 contiguous bytes per wave instruction);
-//   * columns arrive by LDS-DMA, one 16-byte-per-lane instruction per array and column PAIR
-//     (lanes 0-31 the even column, 32-63 the odd one), into a per-wave ring of 3 pairs; one
-//     counted s_waitcnt vmcnt per pair is the only synchronisation, two pairs stay in flight;
+//   * columns arrive by LDS-DMA, two 16-byte-per-lane instructions per array and column PAIR
+//     (main parts, remainders; lanes 0-31 the even column, 32-63 the odd one), into a per-wave
+//     ring of 3 pairs; one counted s_waitcnt vmcnt per pair is the only synchronisation, two
+//     pairs stay in flight;
 //   * the LDS ring only serves as a prefetch buffer that costs no VGPRs and as the source of
 //     the raw inputs of the vertical neighbours (kb / kc clamps in the read address).
 // mpdata_layout.hip converts between this layout and the reference's (upload / download /
@@ -45,14 +53,11 @@ namespace wm {
 
 // arithmetic helpers, DPP shifts and row stores of the x-march kernel
 using v2::dmax; using v2::dmin; using v2::rabs; using v2::rldexp; using v2::andiff; using v2::across;
-using v2::upwind; using v2::pp; using v2::pn; using v2::recip_nr; using v2::st_row; using v2::shift_dn;
+using v2::upwind; using v2::pp; using v2::pn; using v2::recip_nr; using v2::shift_dn;
 using v2::shift_up; using v2::shift_dn_clamped; using v2::shift_up_clamped; using v2::Window;
 
-#ifndef MPDWM_ST_AUX
-#define MPDWM_ST_AUX 0
-#endif
-#ifndef MPDWM_LD_AUX
-#define MPDWM_LD_AUX 0
+#ifndef MPDWM_DEFER_BATCH
+#define MPDWM_DEFER_BATCH 1   // tracer batches defer the odd column's store as well (+3.5 %)
 #endif
 
 template <typename R_, int LPS, int WPB_>
@@ -67,14 +72,17 @@ struct TileWm {
   static constexpr int ARR = 128;               // elements of one array block of a slot (1 KiB)
   static constexpr int SLOT = 3 * ARR;          // f, u, w
   static constexpr int LDS_ELEMS = WPB_ * NS * SLOT;
-  static constexpr int MIN_WAVES = 4;           // 128 VGPRs
+  // 128 VGPRs; one instance per wave (LPS = 64) carries the ghost-level select of w and gets 168
+  static constexpr int MIN_WAVES = LPS == 64 ? 3 : 4;
   static_assert(sizeof(R_) == 8, "8-byte elements (double, or two fp32 instances per lane)");
 };
 
-// COLDMA: column-granular fetch (five columns in flight; best for one tracer, whose inputs come
-// from HBM) instead of pair-granular fetch (fewer instructions; best for tracer batches, which
-// are VALU-bound and read u, w from L2)
-template <typename R, int LPS, int WPB, bool COLDMA>
+// STREAM (one tracer per launch: every byte is used once and the kernel is bound by its data
+// movement): main parts fetched and stored with the streaming hint, remainders with the default
+// policy -- two instructions per array and pair, two per column store.  !STREAM (tracer batches:
+// VALU-bound, u and w are re-read from L2 by the other tracers of the tile): ONE instruction per
+// array and pair / per column store, default policy, every lane addressing its own part.
+template <typename R, int LPS, int WPB, bool STREAM>
 __global__ void __launch_bounds__(64 * WPB, (TileWm<R, LPS, WPB>::MIN_WAVES))
 mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   using T = TileWm<R, LPS, WPB>;
@@ -139,108 +147,147 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   // ---- LDS read positions (elements, relative to `my`): slot, array and column-of-pair are
   //      compile-time offsets on top of these.  The raw inputs of the vertical neighbours are
   //      extra reads with the kb / kc clamps in the address.  Lanes above nzm (ghost level nz
-  //      and dead lanes) read w = 0: element 63 of a column block is never written with data
-  //      (chunk <= 62; LPS = 64 selects instead) and the ring is zeroed at kernel start.
-  const R* const p_own = my + pos;
+  //      and dead lanes) read zeros for f, u and w -- element 63 of a column block is never
+  //      written with data (chunk <= 62; LPS = 64 selects w instead) and the ring is zeroed at
+  //      kernel start: with w = 0 the ghost level's fluxes are exact zeros, which is all the
+  //      level below ever takes from it (www(:,:,:,nz) = 0, :511).
+  const R* const p_own = my + ((LPS == 64 || lvl_ok) ? pos : 63);
   const R* const p_dn = my + (s_l * nzm + (kl > 0 ? kl - 1 : 0));
   const R* const p_up = my + (s_l * nzm + (kl + 1 < nzm ? kl + 1 : nzm - 1));
-  const R* const p_w = (LPS == 64 || lvl_ok) ? p_own : my + 63;
 
   // ---- global addressing: one descriptor per array, based at the wave's tile (32-bit offsets
-  //      inside a tile, arrays of any size).
+  //      inside a tile, arrays of any size).  Element e of column c of the tile lives at
+  //      c*mainB + 8e (e in the main part) or remBase + c*remB + (8e - mainB).
   const unsigned OOB = 0xFFFFFFF8u;
   const int ncol = nx + 6;
+  const unsigned mainB = chunkB / 128u * 128u, remB = chunkB - mainB;
+  const unsigned remBase = (unsigned)ncol * mainB;
   const long long tileB = (long long)ncol * chunkB;
   const __amdgpu_buffer_rsrc_t rsf = v2::make_rsrc(f, tileB);
   const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, tileB);
   const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, tileB);
-  const unsigned st_off = lvl_ok ? (unsigned)(pos * RB) : OOB;  // the lane's element of a chunk
+  const unsigned posB = (unsigned)(pos * RB);
+  const unsigned st_main = (lvl_ok && posB < mainB) ? posB : OOB;               // the lane's element of a chunk:
+  const unsigned st_rem = (lvl_ok && posB >= mainB) ? remBase + (posB - mainB) : OOB;  // in one of the two parts
   // DMA source offsets of a pair instruction: lane L < 32 fetches bytes 16L.. of the even column,
-  // lane L >= 32 bytes 16(L-32).. of the odd one (the LDS image keeps the two columns 512 B apart)
+  // lane L >= 32 bytes 16(L-32).. of the odd one (the LDS image keeps the two columns 512 B apart);
+  // the lanes of a column's main part in the one instruction, those of its remainder in the other
   const unsigned in_col = (unsigned)((lane & 31) * 16);
-  const bool in_ok = in_col < chunkB;
-  const unsigned v_all = in_ok ? in_col + (lane >= 32 ? chunkB : 0u) : OOB;
-  const unsigned v_odd = lane >= 32 ? v_all : OOB;   // only the odd column of the pair
-  const unsigned v_even = lane < 32 ? v_all : OOB;   // only the even one
+  const unsigned hi = lane >= 32 ? 1u : 0u;
+  const bool lane_main = in_col < mainB;
+  const unsigned vA = lane_main ? in_col + hi * mainB : OOB;
+  const unsigned vB = (in_col >= mainB && in_col < chunkB) ? remBase + (in_col - mainB) + hi * remB : OOB;
+  // only the even / only the odd column of a pair: the other half of the lanes out of range
+  auto halves = [&](const unsigned v, const bool e, const bool o) __attribute__((always_inline)) {
+    if (e && o) return v;
+    if (!e && !o) return OOB;
+    unsigned r;
+    const unsigned long long m = e ? 0x00000000FFFFFFFFull : 0xFFFFFFFF00000000ull;
+    asm("v_cndmask_b32 %0, -8, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+    return r;
+  };
+  constexpr int AUX_NT = 2;                      // streaming (non-temporal) cache policy
+  // !STREAM: one instruction serves both parts; a lane's offset advances by its part's pair stride
+  // (running per-lane offsets: the DMA offset advances by the lane's part's pair stride with every
+  //  pair issued -- pairs are issued in order --, the store offset by its column stride with every
+  //  column step; lanes that own nothing keep the out-of-range marker: stride 0)
+  unsigned dcur = lane_main ? vA : vB;
+  // the two per-lane strides share one register: pair stride of the lane's DMA part in the low
+  // half, column stride of its store part in the high half (both <= 1024); a stride is added with
+  // the half-word select of the add itself (SDWA), so unpacking costs no instruction
+  const unsigned pstride = dcur == OOB ? 0u : (lane_main ? 2u * mainB : 2u * remB);
+  const unsigned cstride = lvl_ok ? (posB < mainB ? mainB : remB) : 0u;
+  const unsigned strides = pstride | (cstride << 16);
+  auto add_lo = [](const unsigned a, const unsigned packed) __attribute__((always_inline)) {
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(packed));
+    return r;
+  };
+  auto add_hi = [](const unsigned a, const unsigned packed) __attribute__((always_inline)) {
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(packed));
+    return r;
+  };
+  // store offset of column c = q - 1 of the step about to run; the march starts at q = -2 (and, when
+  // the odd column's store is deferred, with one empty flush that advances the offset as well)
+  unsigned scur = lvl_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) - (3u + (MPDWM_DEFER_BATCH ? 1u : 0u)) * cstride : OOB;
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  auto dma_issue = [&](const int P, const unsigned vf, const unsigned vu, const unsigned vw) __attribute__((always_inline)) {
-    R* d = my + (P % T::NS) * T::SLOT;
-    const unsigned so = (unsigned)(2 * P) * chunkB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)vf, (int)so, 0, MPDWM_LD_AUX);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 16, (int)vu, (int)so, 0, MPDWM_LD_AUX);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 16, (int)vw, (int)so, 0, MPDWM_LD_AUX);
-  };
-  // pair P of all three arrays into its ring slot (3 instructions).  General form: u has no
-  // column c = 0, w none at c = 0 and c = nx+5, nothing exists past the last pair.
-  auto dma_pair = [&](const int P) __attribute__((always_inline)) {
+  // pair P of all three arrays into its ring slot.  e*/o*: which columns of the pair exist for
+  // the array (u has no column c = 0, w none at c = 0 and c = nx+5, nothing exists past the last
+  // column).
+  auto dma_issue = [&](const int P, const bool ef, const bool of, const bool eu, const bool ou, const bool ew,
+                       const bool ow) __attribute__((always_inline)) {
 #ifdef MPDWM_ABL_NODMA  // timing ablation only
     return;
 #endif
-    const int c0 = 2 * P, c1 = 2 * P + 1;  // the pair's columns
-    auto sel = [&](const bool e, const bool o) __attribute__((always_inline)) {
-      return e ? (o ? v_all : v_even) : (o ? v_odd : OOB);
-    };
-    const unsigned vf = sel(c0 < ncol, c1 < ncol);
-    const unsigned vu = sel(c0 >= 1 && c0 < ncol, c1 < ncol);
-    const unsigned vw = sel(c0 >= 1 && c0 <= nx + 4, c1 <= nx + 4);
-    dma_issue(P, vf, vu, vw);
-  };
-  // interior pairs (1 <= P, 2P+1 < nx+5): no conditions
-  auto dma_pair_full = [&](const int P) __attribute__((always_inline)) {
-#ifdef MPDWM_ABL_NODMA
-    return;
-#endif
-    dma_issue(P, v_all, v_all, v_all);
-  };
-
-  // Column-granular fetch (default): column c of the three arrays by three instructions with
-  // lanes 32-63 switched off (27 lanes x 16 bytes each at nz = 28), into the half of its pair's
-  // slot.  Same LDS image as the pair fetch, but a column's slot is free again right after its
-  // own step, so FIVE columns are in flight instead of four (more bytes in flight per CU for
-  // the same LDS), at the price of one counted wait per step.
-  const unsigned v_col = in_ok ? in_col : OOB;
-  auto dma_col_issue = [&](const int c, const unsigned vf, const unsigned vu, const unsigned vw) __attribute__((always_inline)) {
-    R* d = my + ((c >> 1) % T::NS) * T::SLOT + (c & 1) * T::HALF;
-    const unsigned so = (unsigned)c * chunkB;
-    if (lane < 32) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)vf, (int)so, 0, MPDWM_LD_AUX);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 16, (int)vu, (int)so, 0, MPDWM_LD_AUX);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 16, (int)vw, (int)so, 0, MPDWM_LD_AUX);
+    R* d = my + (P % T::NS) * T::SLOT;
+    if constexpr (STREAM) {
+      const unsigned soA = (unsigned)(2 * P) * mainB, soB = (unsigned)(2 * P) * remB;
+      // A lane that is out of range in an LDS-DMA instruction still writes (zeros) to its LDS
+      // position, so the two instructions of an array must not both be executed by a lane: the
+      // main-part fetch runs with the main lanes only, the remainder fetch with the others.
+      if (lane_main) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)halves(vA, ef, of), (int)soA, 0, AUX_NT);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 16, (int)halves(vA, eu, ou), (int)soA, 0, AUX_NT);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 16, (int)halves(vA, ew, ow), (int)soA, 0, AUX_NT);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)halves(vB, ef, of), (int)soB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 16, (int)halves(vB, eu, ou), (int)soB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 16, (int)halves(vB, ew, ow), (int)soB, 0, 0);
+      }
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)halves(dcur, ef, of), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 16, (int)halves(dcur, eu, ou), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 16, (int)halves(dcur, ew, ow), 0, 0, 0);
+      dcur = add_lo(dcur, strides);   // (pairs are issued in order, P = 0, 1, 2, ...)
     }
   };
-  auto dma_col = [&](const int c) __attribute__((always_inline)) {
-#ifdef MPDWM_ABL_NODMA
-    return;
-#endif
-    dma_col_issue(c, c < ncol ? v_col : OOB, (c >= 1 && c < ncol) ? v_col : OOB, (c >= 1 && c <= nx + 4) ? v_col : OOB);
+  auto dma_pair = [&](const int P) __attribute__((always_inline)) {
+    const int c0 = 2 * P, c1 = 2 * P + 1;  // the pair's columns
+    dma_issue(P, c0 < ncol, c1 < ncol, c0 >= 1 && c0 < ncol, c1 < ncol, c0 >= 1 && c0 <= nx + 4, c1 <= nx + 4);
   };
-  auto dma_col_full = [&](const int c) __attribute__((always_inline)) {  // 1 <= c <= nx+4
-#ifdef MPDWM_ABL_NODMA
-    return;
+  // interior pairs (1 <= P, 2P+1 <= nx+4): no conditions
+  auto dma_pair_full = [&](const int P) __attribute__((always_inline)) {
+    dma_issue(P, true, true, true, true, true, true);
+  };
+  // column c of f back to memory.  STREAM: main part with the streaming hint, remainder without
+  // (two instructions); else one instruction, every lane to its part.
+  // AHEAD = 0: the step's regular store (column c = q - 1; advances the running offset);
+  // AHEAD = 2: the early store of a halo column c = q + 1.
+  auto st_col = [&](const bool act, const int c, const R v, auto ahead_tag) __attribute__((always_inline)) {
+    constexpr int AHEAD = decltype(ahead_tag)::value;
+#ifdef MPD2_ABL_NOMEM  // timing ablation only (wrong results)
+    if (v != 1.2345e300) return;
 #endif
-    dma_col_issue(c, v_col, v_col, v_col);
+    const v2::u32x2 b = __builtin_bit_cast(v2::u32x2, v);
+    if constexpr (STREAM) {
+      __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)(act ? st_main : OOB), (int)((unsigned)c * mainB), AUX_NT);
+      __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)(act ? st_rem : OOB), (int)((unsigned)c * remB), 0);
+    } else {
+      // (c is implied by the running offset)
+      unsigned o = scur;
+      if (AHEAD == 2) o = add_hi(add_hi(scur, strides), strides);
+      __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)(act ? o : OOB), 0, 0);
+      if (AHEAD == 0) scur = add_hi(scur, strides);
+    }
   };
 
   // ---- prologue: zero the ring (the never-fetched tails of the column blocks supply w = 0 of
-  //      the ghost level), then pairs 0 and 1 into flight, each behind two dropped stores so
+  //      the ghost level), then pairs 0 and 1 into flight, each behind two dropped column stores so
   //      that the counted wait of the first pairs sees the steady-state op pattern
 #pragma unroll
+#ifdef MPDWM_ABL_NODMA  // timing ablation: arithmetic on (non-zero, finite) stand-in data
+  for (int j = 0; j < T::NS * T::SLOT / 64; ++j) my[j * 64 + lane] = R(0.25) + R(0.001) * R((j * 64 + lane) % 97) - R(0.3) * R(lane & 1);
+#else
   for (int j = 0; j < T::NS * T::SLOT / 64; ++j) my[j * 64 + lane] = R(0);
+#endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if constexpr (!COLDMA) {
 #pragma unroll
-    for (int P = 0; P < T::NS - 1; ++P) {
-      st_row(rsf, OOB, 0, R(0));
-      st_row(rsf, OOB, 0, R(0));
-      dma_pair(P);
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < 2 * T::NS; ++c) {  // columns 0 .. 5, each behind a dropped store
-      st_row(rsf, OOB, 0, R(0));
-      dma_col(c);
-    }
+  for (int P = 0; P < T::NS - 1; ++P) {
+    st_col(false, 0, R(0), std::integral_constant<int, 1>{});
+    st_col(false, 0, R(0), std::integral_constant<int, 1>{});
+    dma_pair(P);
   }
   __builtin_amdgcn_sched_barrier(0);
   const R IRHO = R(1) / RHO;
@@ -259,6 +306,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = R(0);
   }
   R S1 = R(0), S3 = R(0);
+  R v_def = R(0);   // STREAM: the deferred store of a pair's odd column
+  bool act_def = false;
+  int c_def = 0;
 
 
   // One column step.  PH = c mod 3 selects the register ring slots, SL = (c/2) mod 3 the LDS
@@ -271,11 +321,11 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 
     const R f0q = p_own[LO];
     const R uq = p_own[LO + T::ARR];
-    R wq = p_w[LO + 2 * T::ARR];  // ghost level: w = 0
+    R wq = p_own[LO + 2 * T::ARR];  // ghost level: w = 0
     if constexpr (LPS == 64) wq = lvl_ok ? wq : R(0);
 
 #ifdef MPDWM_ABL_NOCOMPUTE  // timing ablation only: data movement without the arithmetic
-    st_row(rsf, (q - 3 >= -1 && q - 3 <= nx + 2) ? st_off : OOB, (unsigned)max(q - 1, 0) * chunkB, f0q + uq + wq);
+    st_col(q - 3 >= -1 && q - 3 <= nx + 2, max(q - 1, 0), f0q + uq + wq, std::integral_constant<int, 0>{});
     return;
 #endif
 #define DN_C(x) shift_dn_clamped((x), own_dn)
@@ -302,7 +352,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         MN0_1 = dmin(S.PMN[C1], f0q);
         // the last two halo columns (nx+1, nx+2) keep this first-pass value (:557) and no later
         // step finishes them: store them now (their input values are already in the LDS ring)
-        if (!FULL && q - 1 >= nx + 1) st_row(rsf, q - 1 <= nx + 2 ? st_off : OOB, (unsigned)(q + 1) * chunkB, f1_1);
+        if (!FULL && q - 1 >= nx + 1) st_col(q - 1 <= nx + 2, q + 1, f1_1, std::integral_constant<int, 2>{});
       }
     }
     S.U1[C0] = U1q;
@@ -415,7 +465,14 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
       R v = S.F1[C3];  // halo columns keep the first-pass value (:557)
       if (FULL || (n >= 1 && n <= nx))
         v = dmax(R(0), S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
-      st_row(rsf, (FULL || act) ? st_off : OOB, (unsigned)max(n + 2, 0) * chunkB, v);
+      // STREAM: the odd column's store waits until the next pair has been waited for -- the
+      // counted wait must see every store issued after the pair's DMA complete, and a
+      // (slow, streaming) store issued right before it would stall it for a store round trip
+      if constexpr ((STREAM || MPDWM_DEFER_BATCH) && decltype(h_tag)::value == 1) {
+        v_def = v; act_def = FULL || act; c_def = max(n + 2, 0);
+      } else {
+        st_col(FULL || act, max(n + 2, 0), v, std::integral_constant<int, 0>{});
+      }
     }
     S.U3[C2] = U3_2;
     S.DW3[C2] = DW3_2;
@@ -435,33 +492,27 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   //   fill (q = -2 .. 3) and drain trips: wave-uniform conditions; steps beyond q = nx+3 do nothing;
   //   steady-state trips (4 <= q, q+5 <= nx): every stage active, no conditions.
   const int q_last = nx + 3;
-  // pair-granular: wait for the pair (2 stores + 3 DMA were issued since its own DMA), two
-  // column steps, fetch pair P+2 into the slot of pair P-1.
-  // column-granular: wait for the column (5 x (1 store + 3 DMA) since its own DMA), the step,
-  // fetch column c+6 into the place of column c.
-  auto dma_p = [&](const int q) __attribute__((always_inline)) {   // q: the column just done
-    if constexpr (COLDMA) dma_col(q + 8);
-    else dma_pair(((q + 1) >> 1) + 2);
-  };
+  // per pair: wait for it (STREAM: 6 DMA instructions, else 3, were issued since its own), two column steps,
+  // fetch pair P+2 into the slot of pair P-1
+  auto dma_p = [&](const int q) __attribute__((always_inline)) { dma_pair(((q + 1) >> 1) + 2); };  // q: odd column of the pair
   auto dma_f = [&](const int q) __attribute__((always_inline)) {
-    if constexpr (COLDMA) {
-      if (q + 8 <= nx + 4) dma_col_full(q + 8); else dma_col(q + 8);
-    } else {
-      const int P = ((q + 1) >> 1) + 2;
-      if (2 * P + 1 < nx + 5) dma_pair_full(P); else dma_pair(P);
-    }
+    const int P = ((q + 1) >> 1) + 2;
+    if (2 * P + 1 <= nx + 4) dma_pair_full(P); else dma_pair(P);
   };
-#define MPDWM_PAIR(PHA, PHB, SL, TAG, q, DMA)                          \
-  if constexpr (COLDMA) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); \
-  else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                 \
-  step(PHA{}, SL{}, I0{}, TAG{}, (q));                                 \
-  asm volatile("" ::: "memory");                                       \
-  if constexpr (COLDMA) {                                              \
-    DMA(q);                                                            \
-    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");                  \
-  }                                                                    \
-  step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1);                             \
-  asm volatile("" ::: "memory");                                       \
+// The counted waits only rely on LOADS returning in issue order: "at most as many operations
+// outstanding as DMA instructions were issued after the pair's own".  (Counting the column stores
+// issued in between as well -- vmcnt(10) / vmcnt(5) -- is a race: a store may be acknowledged
+// before an older load has landed, and the count then drops below the mark with a DMA of the
+// pair still in flight; seen as sporadic wrong columns with default-policy stores.)
+#define MPDWM_FLUSH_DEFERRED if constexpr (STREAM || MPDWM_DEFER_BATCH) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
+#define MPDWM_PAIR(PHA, PHB, SL, TAG, q, DMA)           \
+  if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+  else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  \
+  MPDWM_FLUSH_DEFERRED                                  \
+  step(PHA{}, SL{}, I0{}, TAG{}, (q));                  \
+  asm volatile("" ::: "memory");                        \
+  step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1);              \
+  asm volatile("" ::: "memory");                        \
   DMA((q) + 1);
   int q0 = -2;
   {  // fill: columns -2 .. 3 (nx >= 1: all of them exist)
@@ -481,7 +532,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     MPDWM_PAIR(I1, I2, I2, Part, q0 + 4, dma_p)
   }
 #undef MPDWM_PAIR
+#undef MPDWM_FLUSH_DEFERRED
 
+  if constexpr (STREAM || MPDWM_DEFER_BATCH) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
   if (lvl_ok) flux[pos] = S1 + S3;  // :541-547, :624
 }
 

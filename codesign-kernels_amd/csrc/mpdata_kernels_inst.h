@@ -1,6 +1,7 @@
 // mpdata_kernels_inst.h -- instantiates the tilings of one arithmetic variant.
 // Included by mpdata_kernels_exact.hip / mpdata_kernels_fast.hip after
 // defining MPDATA_NS; exports <MPDATA_NS>::launch(tile, ...).
+#include <cstdlib>
 #include "mpdata_kernel_body.h"
 #include "mpdata_kernel_v2_body.h"
 #include "mpdata_kernel_wm_body.h"
@@ -72,8 +73,15 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
 #define MPDATA_WM_LPS(X) X(8) X(16) X(32) X(64)
 template <int LPS, int WPB>
 static void launch_wm_t(const MpdataWmArgs& a, void* stream) {
-  // ntracers == 1: wave = tile in dispatch order; else the per-XCD tracer walk (see the kernel)
-  if (a.ntracers == 1) {
+  // ntracers == 1: wave = tile in dispatch order, u and w streamed; else the per-XCD tracer walk with
+  // u, w kept in L2 (see the kernel)
+  // MPDATA_WM_NOSTREAM (tests): run the batch form of the kernel on a single tracer as well
+  const bool no_stream = getenv("MPDATA_WM_NOSTREAM") != nullptr;
+  if (a.ntracers == 1 && no_stream) {
+    const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS, WPB, false>), dim3(blocks), dim3(64 * WPB), 0,
+                       (hipStream_t)stream, a);
+  } else if (a.ntracers == 1) {
     const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);
     hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS, WPB, true>), dim3(blocks), dim3(64 * WPB), 0,
                        (hipStream_t)stream, a);

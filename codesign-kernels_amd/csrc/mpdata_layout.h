@@ -8,8 +8,11 @@
 //       ref + tr*ref_tstride + sl + ncrms*(cs*ref_colmul + kk*ref_levmul)
 //     f, u, w: ref_colmul = 1, ref_levmul = number of columns; rho, rhow, adz, flux: one
 //     column, ref_levmul = 1
-//   private side: element (tile t, column cs + prv_col0, instance-in-tile s, level kk) at
-//       prv + tr*prv_tstride + t*prv_tile_stride + (cs + prv_col0)*chunk + s*nlev + kk
+//   private side: element e = s*nlev + kk (instance-in-tile s, level kk) of column
+//   c = cs + prv_col0 of tile t at prv + tr*prv_tstride + t*prv_tile_stride +
+//       c*chunk + e                                              (main_e == 0: unsplit arrays)
+//       c*main_e + e                    if e <  main_e           (f, u, w: the whole 128-byte
+//       ncol_p*main_e + c*rem_e + e - main_e   otherwise          lines of a column first)
 struct MpdataLayoutJob {
   void* ref;
   void* prv;
@@ -22,6 +25,8 @@ struct MpdataLayoutJob {
   int ntiles;
   int prv_col0;              // column shift: u, w start at c = 1 of the private column index
   long long chunk;           // slp * nlev
+  long long main_e;          // elements of the line-aligned part of a column chunk (0: array not split)
+  int ncol_p;                // column slots of a tile on the private side (split arrays)
   long long prv_tile_stride, prv_tstride;
 };
 

@@ -3,6 +3,8 @@
 // mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:33-38) and the plan-private
 // "wave-major" layout of mpdata_kernel_wm_body.h:
 //     [tracer][tile][column][instance-in-tile][level]      (level fastest)
+// with, for f, u and w, every column chunk split into its whole 128-byte lines (stored first,
+// column after column) and the rest (stored behind them).
 // A workgroup moves all levels of 64 consecutive instances of one column through an LDS tile:
 // the reference side is read/written in 512-byte row segments, the private side in the
 // contiguous chunks of 64/slp tiles.  These kernels run in upload / download / device
@@ -38,7 +40,10 @@ __global__ void __launch_bounds__(256) wm_convert_kernel(const MpdataLayoutJob j
   auto prv_at = [&](long long inst, int kk) -> long long {
     const long long t = inst / slp;
     const int s = (int)(inst - t * slp);
-    return t * j.prv_tile_stride + (long long)(cs + j.prv_col0) * j.chunk + s * nlev + kk;
+    const long long e = (long long)s * nlev + kk, c = cs + j.prv_col0;
+    if (j.main_e == 0) return t * j.prv_tile_stride + c * j.chunk + e;
+    const long long rem_e = j.chunk - j.main_e;
+    return t * j.prv_tile_stride + (e < j.main_e ? c * j.main_e + e : j.ncol_p * j.main_e + c * rem_e + (e - j.main_e));
   };
   if (TO_PRIVATE) {
     for (int i = tid; i < n; i += 256) {

@@ -96,6 +96,22 @@ def test_wavemajor_plan_shapes(M, oracle, shape, variant, dist):
     assert np.array_equal(flux[:, -1], inp["flux"][:, -1])
 
 
+@pytest.mark.parametrize("shape", [(64, 32, 28), (37, 32, 17), (21, 33, 33), (10, 6, 64), (258, 31, 28), (7, 2, 4)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_batch_form_of_the_kernel_on_single_tracers(M, oracle, monkeypatch, shape, variant):
+    """The kernel has two forms (mpdata_kernel_wm_body.h): streaming fetch / store for one tracer per
+    launch, default cache policy with one instruction per array for tracer batches.
+    MPDATA_WM_NOSTREAM runs the batch form on single-tracer problems, so that it sees all the shapes."""
+    monkeypatch.setenv("MPDATA_WM_NOSTREAM", "1")
+    var = M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST
+    M.set_variant(var)
+    inp = oracle.make_inputs(*shape, seed=13, dist=3)
+    f, flux = run_plan_host(M, inp)
+    f_ref, flux_ref = oracle.advect(inp, nthreads=4)
+    assert_parity(M, oracle, var, 3, f, flux, f_ref, flux_ref)
+
+
 @pytest.mark.parametrize("variant", ["exact", "fast"])
 def test_wavemajor_tracer_batch_and_subranges(M, oracle, variant):
     """T tracers sharing u, w, rho, rhow, adz == T single-tracer calls of the oracle; a sub-range

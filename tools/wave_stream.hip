@@ -21,11 +21,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
 // MODE 2: register loads (buffer_load_dwordx2 per lane), software pipeline depth NS columns
 template <int MODE, int NS, int WPB, int LA = 0, int SA = 0>
 __global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, const char* w, char* fo,
-                                                  int ntiles, int ncol, int chunkB, long long tileB) {
+                                                  int ntiles, int ncol, int chunkB, long long tileB, int tmap) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x * WPB + wave;
+  int tile = blockIdx.x * WPB + wave;
   if (tile >= ntiles) return;
+  if (tmap == 1) {   // XCD-contiguous: the blocks an XCD receives (b % 8) walk one eighth of the tiles
+    const int nb = gridDim.x, per = nb / 8;
+    const int b = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    tile = b * WPB + wave;
+  } else if (tmap == 2) {  // CU-contiguous-ish: 32 consecutive blocks of an XCD get adjacent tiles
+    const int b = blockIdx.x;
+    const int x = b % 8, j = b / 8;
+    tile = ((j / 32) * 8 * 32 + x * 32 + j % 32) * WPB + wave;
+  }
   // descriptors relative to this wave's tile (arrays may exceed 4 GiB)
   const __amdgpu_buffer_rsrc_t rf = make_rsrc(f + tile * tileB, tileB);
   const __amdgpu_buffer_rsrc_t ru = make_rsrc(u + tile * tileB, tileB);
@@ -95,6 +104,137 @@ __global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, 
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)st_off, (int)(c * chunkB), SA);
       dma(c + NS - 1);
     }
+  } else if constexpr (MODE == 3) {
+    // split layout: per tile [col][mainB] (line-aligned part of every column chunk) followed by
+    // [col][remB]; main part fetched / stored non-temporally (policy LA / SA), remainder cached
+    __shared__ double lds[WPB * NS * 3 * 128];
+    double* my = lds + wave * NS * 3 * 128;
+    const int mainB = chunkB / 128 * 128, remB = chunkB - mainB;
+    const unsigned remBase = (unsigned)(ncol * mainB);
+    const int l32 = lane & 31;
+    const unsigned hi = lane >= 32 ? 1u : 0u;
+    const unsigned vA = l32 * 16 < mainB ? (unsigned)(l32 * 16) + hi * mainB : OOB;
+    const unsigned vB = (l32 * 16 >= mainB && l32 * 16 < chunkB) ? remBase + (unsigned)(l32 * 16 - mainB) + hi * remB : OOB;
+    const unsigned sA = lane * 8 < mainB ? lane * 8 : OOB;
+    const unsigned sB = (lane * 8 >= mainB && lane * 8 < chunkB) ? remBase + (unsigned)(lane * 8 - mainB) : OOB;
+    const int npair = ncol / 2;
+    auto dma = [&](int p) __attribute__((always_inline)) {
+      if (p >= npair) p = npair - 1;
+      double* d = my + (p % NS) * 3 * 128;
+      const unsigned soA = (unsigned)(p * 2 * mainB), soB = (unsigned)(p * 2 * remB);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_ptr_t)d, 16, (int)vA, (int)soA, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(d + 128), 16, (int)vA, (int)soA, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(d + 256), 16, (int)vA, (int)soA, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_ptr_t)d, 16, (int)vB, (int)soB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(d + 128), 16, (int)vB, (int)soB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(d + 256), 16, (int)vB, (int)soB, 0, 0);
+    };
+    for (int p = 0; p < NS - 1; ++p) {
+      for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0, 0}, ro, (int)OOB, 0, 0);
+      dma(p);
+    }
+    for (int p = 0; p < npair; ++p) {
+      static_assert(NS == 3, "");
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      const double* s = my + (p % NS) * 3 * 128;
+      const int kl = lane * 8 < chunkB ? lane : 0;
+      const double a0 = s[kl] + s[128 + kl] + s[256 + kl];
+      const double a1 = s[64 + kl] + s[128 + 64 + kl] + s[256 + 64 + kl];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)sA, (int)(p * 2 * mainB), SA);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)sB, (int)(p * 2 * remB), 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)sA, (int)((p * 2 + 1) * mainB), SA);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)sB, (int)((p * 2 + 1) * remB), 0);
+      dma(p + NS - 1);
+    }
+  } else if constexpr (MODE == 4) {
+    // main parts [col][mainB] + one 128-byte line per column PAIR holding both remainders: one
+    // fetch instruction per array and pair, every line touched exactly once; stores: main part
+    // (policy SA) + remainder (default policy)
+    __shared__ double lds[WPB * NS * 3 * 128];
+    double* my = lds + wave * NS * 3 * 128;
+    const int mainB = chunkB / 128 * 128, remB = chunkB - mainB;
+    const int npair = ncol / 2;
+    const unsigned remBase = (unsigned)(ncol * mainB);
+    const int l32 = lane & 31;
+    const unsigned hi = lane >= 32 ? 1u : 0u;
+    const unsigned vM = l32 * 16 < mainB ? (unsigned)(l32 * 16) + hi * mainB : OOB;
+    const unsigned vR = (l32 * 16 >= mainB && l32 * 16 < chunkB) ? remBase + (unsigned)(l32 * 16 - mainB) + hi * remB : OOB;
+    const bool isM = l32 * 16 < mainB;
+    const unsigned sA = lane * 8 < mainB ? lane * 8 : OOB;
+    const unsigned sB = (lane * 8 >= mainB && lane * 8 < chunkB) ? remBase + (unsigned)(lane * 8 - mainB) : OOB;
+    auto dma = [&](int p) __attribute__((always_inline)) {
+      if (p >= npair) p = npair - 1;
+      double* d = my + (p % NS) * 3 * 128;
+      // per-lane byte offset: main lanes advance 2*mainB per pair, remainder lanes 128 per pair
+      const unsigned v = isM ? vM + (unsigned)(p * 2 * mainB) : (vR == OOB ? OOB : vR + (unsigned)(p * 128));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_ptr_t)d, 16, (int)v, 0, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(d + 128), 16, (int)v, 0, 0, LA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(d + 256), 16, (int)v, 0, 0, LA);
+    };
+    for (int p = 0; p < NS - 1; ++p) {
+      for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0, 0}, ro, (int)OOB, 0, 0);
+      dma(p);
+    }
+    for (int p = 0; p < npair; ++p) {
+      static_assert(NS == 3, "");
+      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      const double* s = my + (p % NS) * 3 * 128;
+      const int kl = lane * 8 < chunkB ? lane : 0;
+      const double a0 = s[kl] + s[128 + kl] + s[256 + kl];
+      const double a1 = s[64 + kl] + s[128 + 64 + kl] + s[256 + 64 + kl];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)sA, (int)(p * 2 * mainB), SA);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)sB, (int)(p * 128), 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)sA, (int)((p * 2 + 1) * mainB), SA);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)(sB == OOB ? OOB : sB + remB), (int)(p * 128), 0);
+      dma(p + NS - 1);
+    }
+  } else if constexpr (MODE == 5) {
+    // MODE 3 with the two fetch instructions of an array executed by disjoint lane sets (EXEC)
+    __shared__ double lds[WPB * NS * 3 * 128];
+    double* my = lds + wave * NS * 3 * 128;
+    const int mainB = chunkB / 128 * 128, remB = chunkB - mainB;
+    const unsigned remBase = (unsigned)(ncol * mainB);
+    const int l32 = lane & 31;
+    const unsigned hi = lane >= 32 ? 1u : 0u;
+    const bool isM = l32 * 16 < mainB;
+    const unsigned vA = isM ? (unsigned)(l32 * 16) + hi * mainB : OOB;
+    const unsigned vB = (l32 * 16 >= mainB && l32 * 16 < chunkB) ? remBase + (unsigned)(l32 * 16 - mainB) + hi * remB : OOB;
+    const unsigned sA = lane * 8 < mainB ? lane * 8 : OOB;
+    const unsigned sB = (lane * 8 >= mainB && lane * 8 < chunkB) ? remBase + (unsigned)(lane * 8 - mainB) : OOB;
+    const int npair = ncol / 2;
+    auto dma = [&](int p) __attribute__((always_inline)) {
+      if (p >= npair) p = npair - 1;
+      double* d = my + (p % NS) * 3 * 128;
+      const unsigned soA = (unsigned)(p * 2 * mainB), soB = (unsigned)(p * 2 * remB);
+      if (isM) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_ptr_t)d, 16, (int)vA, (int)soA, 0, LA);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(d + 128), 16, (int)vA, (int)soA, 0, LA);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(d + 256), 16, (int)vA, (int)soA, 0, LA);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_ptr_t)d, 16, (int)vB, (int)soB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(d + 128), 16, (int)vB, (int)soB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(d + 256), 16, (int)vB, (int)soB, 0, 0);
+      }
+    };
+    for (int p = 0; p < NS - 1; ++p) {
+      for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0, 0}, ro, (int)OOB, 0, 0);
+      dma(p);
+    }
+    for (int p = 0; p < npair; ++p) {
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      const double* s = my + (p % NS) * 3 * 128;
+      const int kl = lane * 8 < chunkB ? lane : 0;
+      const double a0 = s[kl] + s[128 + kl] + s[256 + kl];
+      const double a1 = s[64 + kl] + s[128 + 64 + kl] + s[256 + 64 + kl];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)sA, (int)(p * 2 * mainB), SA);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)sB, (int)(p * 2 * remB), 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)sA, (int)((p * 2 + 1) * mainB), SA);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)sB, (int)((p * 2 + 1) * remB), 0);
+      dma(p + NS - 1);
+    }
   } else {
     // register-staged: NS columns of (f,u,w) in flight per lane
     double rf_[NS], ru_[NS], rw_[NS];
@@ -120,42 +260,40 @@ __global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, 
 }
 
 template <int MODE, int NS, int WPB, int LA = 0, int SA = 0>
-void run(const char* f, const char* u, const char* w, char* fo, int ntiles, int ncol, int chunkB, long long tileB, const char* tag) {
+void run(const char* f, const char* u, const char* w, char* fo, int ntiles, int ncol, int chunkB, long long tileB, const char* tag, int tmap = 0, int ldsper = 10240) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int blocks = (ntiles + WPB - 1) / WPB;
   // occupancy as in the real kernel (128 VGPRs: 16 waves per CU): pad every wave to 10 KB of LDS
-  const int stat = MODE == 0 ? NS * 3 * 1024 : MODE == 1 ? NS * 3 * 512 : 0;
-  const int dyn = stat < 10240 ? WPB * (10240 - stat) : 0;
+  const int stat = (MODE == 0 || MODE >= 3) ? NS * 3 * 1024 : MODE == 1 ? NS * 3 * 512 : 0;
+  const int dyn = stat < ldsper ? WPB * (ldsper - stat) : 0;
   for (int r = 0; r < 60; ++r)
-    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB);
+    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB, tmap);
   (void)hipEventRecord(e0);
   for (int r = 0; r < 60; ++r)
-    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB);
+    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB, tmap);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 60;
   const double bytes = (double)ntiles * ncol * chunkB * 4;
-  printf("%-10s LA %d SA %d mode %d ring %d waves/wg %d tileB %lld: %.3f ms  %.2f TB/s (err %d)\n", tag, LA, SA, MODE, NS, WPB, tileB, ms,
+  printf("%-10s tmap %d lds/wave %d LA %d SA %d mode %d ring %d waves/wg %d tileB %lld: %.3f ms  %.2f TB/s (err %d)\n", tag, tmap, ldsper, LA, SA, MODE, NS, WPB, tileB, ms,
          bytes / (ms * 1e-3) / 1e12, (int)hipGetLastError());
 }
 
 int main(int argc, char** argv) {
-  const int ntiles = 32768, ncol = 38;
-  for (int chunkB : {432, 448, 512}) {
-    const long long tileB = 38ll * chunkB;
-    const size_t n = (size_t)ntiles * tileB;
+  const int ntiles = 32768, ncol = 38, chunkB = 432;
+  {
+    const long long tileB = 38ll * 432 + 96;   // 16512 = 129 lines
+    const size_t n = (size_t)ntiles * 17024;
     char *f, *u, *w, *fo;
     (void)hipMalloc(&f, n + 8192); (void)hipMalloc(&u, n + 8192); (void)hipMalloc(&w, n + 8192); (void)hipMalloc(&fo, n + 8192);
     (void)hipMemset(f, 0, n); (void)hipMemset(u, 0, n); (void)hipMemset(w, 0, n); (void)hipMemset(fo, 0, n);
-    const char* uu = u; const char* ww = w;
-    printf("---- chunk %d B (TB/s counts the bytes actually moved; x %.3f = algorithmic at 432 B)\n", chunkB, 432.0 / chunkB);
-    run<0, 3, 1>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
-    run<0, 3, 4>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
-    run<0, 3, 4, 2, 0>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
-    run<0, 3, 4, 0, 2>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
-    run<0, 3, 4, 2, 2>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
-    run<2, 4, 4, 0, 0>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
-    run<2, 4, 4, 2, 2>(f, uu, ww, f, ntiles, ncol, chunkB, tileB, "in place");
-    (void)hipFree(f); (void)hipFree(u); (void)hipFree(w); (void)hipFree(fo);
+    for (int rep = 0; rep < 2; ++rep) {
+      run<0, 3, 4>(f, u, w, f, ntiles, ncol, chunkB, tileB, "plain");
+      run<3, 3, 4, 2, 2>(f, u, w, f, ntiles, ncol, chunkB, tileB, "split OOB");
+      run<5, 3, 4, 2, 2>(f, u, w, f, ntiles, ncol, chunkB, tileB, "splitEXEC");
+      run<4, 3, 4, 2, 2>(f, u, w, f, ntiles, ncol, chunkB, 17024, "pair-line");   // 38*384 + 19*128 = 133 lines
+      run<4, 3, 4, 0, 2>(f, u, w, f, ntiles, ncol, chunkB, 17024, "pair-line");
+      run<4, 3, 4, 0, 0>(f, u, w, f, ntiles, ncol, chunkB, 17024, "pair-line");
+    }
   }
   return 0;
 }
