@@ -272,7 +272,7 @@ PREWARM_MS = 60.0  # --prewarm-ms
 # VALU instructions one wave executes per call at nx=32, nz=28 (rocprofv3 SQ_INSTS_VALU / SQ_WAVES,
 # profiles/r02_pmc_summary.json) and the measured fp64 VALU issue peak of the chip
 # (tools/valu_rate.hip: 33e12 lane-ops/s = 515.6e9 wave-instructions/s)
-VALU_PER_WAVE_NX32_NZ28 = {"fast": 4305.0, "exact": None}
+VALU_PER_WAVE_NX32_NZ28 = {"fast": 4289.0, "exact": None}
 VALU_PEAK_WAVE_INSTR_PER_S = 33.0e12 / 64.0
 
 
