@@ -545,14 +545,21 @@ def main():
 
         s3 = min(steps, 40)
         dt3, kms3 = timed_loop(torch, dist, world, launch32, s3, min(warmup, 20))
+        del fs3
+        torch.cuda.empty_cache()
+        # ... and through an fp32 plan (wave-major layout, two instances per lane)
+        dt5, kms5, info5 = bench_plan(M, torch, dist, world, dev, sh32, sh_f1, n_loc, n_glob, sl0, nx, nz, 1, s3,
+                                      min(warmup, 20), args.dist, np.float32, torch.float32, 0.3 * mem_frac)
         if rank == 0:
             ab = M.algorithmic_bytes(n_loc, nx, nz, 1, f32=True)
             result["fp32"] = {
-                "workload": f"ncrms={n_loc}/GPU nx={nx} nz={nz} fp32, 1 tracer (mpdata_advect_scalar2d_f32_device, "
-                            "reference layout)",
-                "value": cells_1 * s3 / dt3, "unit": "cell-updates/s", "steps": s3,
-                "ms_per_step": dt3 / s3 * 1e3, "roofline": roofline_block(ab, kms3)}
-        del fs3, sh32
+                "workload": f"ncrms={n_loc}/GPU nx={nx} nz={nz} fp32, 1 tracer, plan API ({info5['layout']})",
+                "value": cells_1 * s3 / dt5, "unit": "cell-updates/s", "steps": s3,
+                "ms_per_step": dt5 / s3 * 1e3, "roofline": roofline_block(ab, kms5),
+                "reference_layout_device_call": {
+                    "workload": "mpdata_advect_scalar2d_f32_device on reference-layout device arrays (x-march kernel)",
+                    "value": cells_1 * s3 / dt3, "ms_per_step": dt3 / s3 * 1e3, "roofline": roofline_block(ab, kms3)}}
+        del sh32
         torch.cuda.empty_cache()
 
     # ---- side measurement: the second / third kernel, rank 0 only ----------

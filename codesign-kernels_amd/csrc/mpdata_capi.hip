@@ -305,8 +305,14 @@ int mpdata_advect_scalar2d_f32_device(int64_t ncrms, int nx, int nz, int ntracer
 // fp64 plans with nz <= 64 keep the arrays in the wave-major layout of
 // mpdata_kernel_wm_body.h and convert in upload / download / import / export; other plans
 // (fp32; nz > 64) keep the reference layout and run the x-/k-marching kernels.
-namespace mpdata_exact { bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream); }
-namespace mpdata_fast { bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream); }
+namespace mpdata_exact {
+bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream);
+bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream);
+}
+namespace mpdata_fast {
+bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream);
+bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream);
+}
 
 namespace {
 int g_layout = -1;  // -1: read MPDATA_PLAN_LAYOUT on first use
@@ -351,6 +357,7 @@ struct mpdata_plan {
   void *f, *u, *w, *rho, *rhow, *adz, *flux;  // = arena.p[0..6]
   // wave-major plans
   int lps, slp, wpb, ntiles;
+  int64_t wm_ncrms;  // instances as the wave-major side sees them: ncrms (fp64) or ncrms / 2 pairs (fp32)
   long long chunk, tile_elems, main_e;   // main_e: elements of the line-aligned part of a column chunk
   void *pf, *pu, *pw, *pkc, *pflux;  // private arrays
   void* stage;                       // reference-layout staging: one tracer of f (or u, w)
@@ -370,7 +377,8 @@ namespace {
 MpdataLayoutJob wm_job(const mpdata_plan* p, int which, void* ref, int first_tracer, int ntr) {
   MpdataLayoutJob j;
   const int nzm = p->nz - 1, nx = p->nx;
-  j.ref = ref; j.ncrms = p->ncrms; j.nlev = nzm; j.ntr = 1; j.slp = p->slp; j.ntiles = p->ntiles;
+  // (fp32 plans: every array seen as wm_ncrms = ncrms / 2 pairs of adjacent instances, 8 bytes each)
+  j.ref = ref; j.ncrms = p->wm_ncrms; j.nlev = nzm; j.ntr = 1; j.slp = p->slp; j.ntiles = p->ntiles;
   j.chunk = p->chunk; j.ref_tstride = 0; j.prv_tstride = 0; j.prv_col0 = 0;
   j.main_e = which <= 2 ? p->main_e : 0;   // f, u, w are split into line-aligned part + rest
   j.ncol_p = nx + 6;
@@ -379,7 +387,7 @@ MpdataLayoutJob wm_job(const mpdata_plan* p, int which, void* ref, int first_tra
     case 0:
       j.prv = (double*)p->pf + (long long)first_tracer * p->ntiles * p->tile_elems;
       j.ncols = nx + 6; j.ref_levmul = nx + 6; j.prv_tile_stride = p->tile_elems;
-      j.ntr = ntr; j.ref_tstride = (long long)p->ncrms * (nx + 6) * nzm; j.prv_tstride = (long long)p->ntiles * p->tile_elems;
+      j.ntr = ntr; j.ref_tstride = (long long)p->wm_ncrms * (nx + 6) * nzm; j.prv_tstride = (long long)p->ntiles * p->tile_elems;
       break;
     case 1: j.prv = p->pu; j.ncols = nx + 5; j.ref_levmul = nx + 5; j.prv_col0 = 1; j.prv_tile_stride = p->tile_elems; break;
     case 2: j.prv = p->pw; j.ncols = nx + 4; j.ref_levmul = nx + 4; j.prv_col0 = 1; j.prv_tile_stride = p->tile_elems; break;
@@ -390,7 +398,7 @@ MpdataLayoutJob wm_job(const mpdata_plan* p, int which, void* ref, int first_tra
     default:
       j.prv = (double*)p->pflux + (long long)first_tracer * p->ntiles * p->chunk;
       j.ncols = 1; j.ref_colmul = 0; j.ref_levmul = 1; j.prv_tile_stride = p->chunk;
-      j.ntr = ntr; j.ref_tstride = (long long)p->ncrms * p->nz; j.prv_tstride = (long long)p->ntiles * p->chunk;
+      j.ntr = ntr; j.ref_tstride = (long long)p->wm_ncrms * p->nz; j.prv_tstride = (long long)p->ntiles * p->chunk;
       break;
   }
   return j;
@@ -434,13 +442,13 @@ int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, con
       HIP_TRY(hipMemcpyAsync(p->stage, src, elems * eb, hipMemcpyHostToDevice, p->stream));
       ref = p->stage;
     }
-    HIP_TRY(mpdata_layout_convert(wm_job(p, which, ref, tr, 1), eb, true, p->stream));
+    HIP_TRY(mpdata_layout_convert(wm_job(p, which, ref, tr, 1), 8, true, p->stream));
     return 0;
   };
   int rc = 0;
   if (f) {
     if (dev) {
-      HIP_TRY(mpdata_layout_convert(wm_job(p, 0, const_cast<void*>(f), first, count), eb, true, p->stream));
+      HIP_TRY(mpdata_layout_convert(wm_job(p, 0, const_cast<void*>(f), first, count), 8, true, p->stream));
     } else {
       for (int t = 0; t < count && !rc; ++t) rc = one(0, (const char*)f + (size_t)t * f1 * eb, f1, first + t);
     }
@@ -455,7 +463,7 @@ int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, con
     // private array (a tracer that is never run exports what was imported)
     void* fr = (char*)p->flux_ref + (size_t)first * p->sz.kz * eb;
     HIP_TRY(hipMemcpyAsync(fr, flux, p->sz.kz * count * eb, kind, p->stream));
-    HIP_TRY(mpdata_layout_convert(wm_job(p, 6, fr, first, count), eb, true, p->stream));
+    HIP_TRY(mpdata_layout_convert(wm_job(p, 6, fr, first, count), 8, true, p->stream));
   }
   return rc;
 }
@@ -471,10 +479,10 @@ int plan_export(mpdata_plan* p, void* f, void* flux, int first, int count, bool 
   }
   if (f) {
     if (dev) {
-      HIP_TRY(mpdata_layout_convert(wm_job(p, 0, f, first, count), eb, false, p->stream));
+      HIP_TRY(mpdata_layout_convert(wm_job(p, 0, f, first, count), 8, false, p->stream));
     } else {
       for (int t = 0; t < count; ++t) {
-        HIP_TRY(mpdata_layout_convert(wm_job(p, 0, p->stage, first + t, 1), eb, false, p->stream));
+        HIP_TRY(mpdata_layout_convert(wm_job(p, 0, p->stage, first + t, 1), 8, false, p->stream));
         HIP_TRY(hipMemcpyAsync((char*)f + (size_t)t * f1 * eb, p->stage, f1 * eb, hipMemcpyDeviceToHost, p->stream));
       }
     }
@@ -483,7 +491,7 @@ int plan_export(mpdata_plan* p, void* f, void* flux, int first, int count, bool 
     // levels 1..nzm from the kernel's result; level nz is whatever was uploaded (the reference
     // never writes it, :541, :624)
     void* fr = (char*)p->flux_ref + (size_t)first * p->sz.kz * eb;
-    HIP_TRY(mpdata_layout_convert(wm_job(p, 6, fr, first, count), eb, false, p->stream));
+    HIP_TRY(mpdata_layout_convert(wm_job(p, 6, fr, first, count), 8, false, p->stream));
     HIP_TRY(hipMemcpyAsync(flux, fr, p->sz.kz * count * eb, kind, p->stream));
   }
   return 0;
@@ -499,8 +507,9 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
   const int var = variant();
-  const bool wmaj = eb == 8 && wm_lps_for(nz) != 0 && plan_layout_default() == MPDATA_LAYOUT_WAVEMAJOR &&
-                    tile_override() < 0;
+  // wave-major: fp64, and fp32 with an even ncrms (two adjacent instances per lane = 8-byte elements)
+  const bool wmaj = (eb == 8 || (ncrms & 1) == 0) && wm_lps_for(nz) != 0 &&
+                    plan_layout_default() == MPDATA_LAYOUT_WAVEMAJOR && tile_override() < 0;
   MpdataTileInfo t;
   if (!wmaj) {
     rc = choose_tile(var, ncrms, nx, nz, &t, eb);
@@ -524,24 +533,26 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   }
   if (e == hipSuccess && wmaj) {
     const int nzm = nz - 1;
+    const int web = 8;   // bytes of an element on the wave-major side (fp32: a pair of instances)
+    p->wm_ncrms = eb == 8 ? ncrms : ncrms / 2;
     p->lps = wm_lps_for(nz); p->slp = 64 / p->lps; p->wpb = wm_wpb();
-    p->ntiles = (int)((ncrms + p->slp - 1) / p->slp);
+    p->ntiles = (int)((p->wm_ncrms + p->slp - 1) / p->slp);
     p->chunk = (long long)p->slp * nzm;
-    p->main_e = p->chunk * eb / 128 * (128 / eb);
+    p->main_e = p->chunk * web / 128 * (128 / web);
     {  // tiles start on 128-byte lines, an ODD number of lines apart (a power-of-two-ish stride
        // would put the same column of every tile on the same HBM channels: measured -5 %)
-      long long lines = ((long long)(nx + 6) * p->chunk * eb + 127) / 128;
+      long long lines = ((long long)(nx + 6) * p->chunk * web + 127) / 128;
       if ((lines & 1) == 0) ++lines;
-      p->tile_elems = lines * (128 / eb);
+      p->tile_elems = lines * (128 / web);
     }
-    const size_t tile_arr = (size_t)p->ntiles * p->tile_elems * eb;
+    const size_t tile_arr = (size_t)p->ntiles * p->tile_elems * web;
     const size_t f1 = p->sz.f / ntracers;
     p->stage_elems = f1 > p->sz.w ? f1 : p->sz.w;
     if (e == hipSuccess) e = hipMalloc(&p->pf, tile_arr * ntracers);
     if (e == hipSuccess) e = hipMalloc(&p->pu, tile_arr);
     if (e == hipSuccess) e = hipMalloc(&p->pw, tile_arr);
-    if (e == hipSuccess) e = hipMalloc(&p->pkc, (size_t)p->ntiles * 3 * p->chunk * eb);
-    if (e == hipSuccess) e = hipMalloc(&p->pflux, (size_t)p->ntiles * p->chunk * ntracers * eb);
+    if (e == hipSuccess) e = hipMalloc(&p->pkc, (size_t)p->ntiles * 3 * p->chunk * web);
+    if (e == hipSuccess) e = hipMalloc(&p->pflux, (size_t)p->ntiles * p->chunk * ntracers * web);
     if (e == hipSuccess) e = hipMalloc(&p->stage, p->stage_elems * eb);
     if (e == hipSuccess) e = hipMalloc(&p->flux_ref, p->sz.kz * ntracers * eb);
     // u, w have column slots that nothing ever fills or fetches (c = 0; c = nx+5 of w)
@@ -583,7 +594,7 @@ static int plan_upload(mpdata_plan* p, const void* f, const void* u, const void*
   if (!flux) {
     HIP_TRY(hipMemsetAsync(fl, 0, p->sz.kz * p->ntracers * eb, p->stream));
     if (p->layout == MPDATA_LAYOUT_WAVEMAJOR)
-      HIP_TRY(hipMemsetAsync(p->pflux, 0, (size_t)p->ntiles * p->chunk * p->ntracers * eb, p->stream));
+      HIP_TRY(hipMemsetAsync(p->pflux, 0, (size_t)p->ntiles * p->chunk * p->ntracers * 8, p->stream));
   }
   rc = plan_import(p, f, u, w, rho, rhow, adz, flux, 0, p->ntracers, false);
   if (rc) return rc;
@@ -648,8 +659,11 @@ int mpdata_plan_run_tracers(mpdata_plan* p, int first, int count) {
     a.f_tstride = (long long)p->ntiles * p->tile_elems;
     a.flux_tstride = (long long)p->ntiles * p->chunk;
     a.reverse = serpentine() ? (int)(p->runs++ & 1u) : 0;
-    const bool ok = p->variant == MPDATA_VARIANT_FAST ? mpdata_fast::launch_wm(p->lps, p->wpb, a, (void*)p->stream)
-                                                      : mpdata_exact::launch_wm(p->lps, p->wpb, a, (void*)p->stream);
+    const bool fast = p->variant == MPDATA_VARIANT_FAST;
+    const bool ok = p->eb == 8 ? (fast ? mpdata_fast::launch_wm(p->lps, p->wpb, a, (void*)p->stream)
+                                       : mpdata_exact::launch_wm(p->lps, p->wpb, a, (void*)p->stream))
+                               : (fast ? mpdata_fast::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream)
+                                       : mpdata_exact::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream));
     if (!ok) return set_err(MPDATA_EINVAL, "wave-major kernel LPS=%d WPB=%d not instantiated", p->lps, p->wpb);
     HIP_TRY(hipGetLastError());
   } else {

@@ -71,33 +71,54 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
 // wave-major kernels (mpdata_kernel_wm_body.h, the plan API): LPS = lanes per instance (>= nz),
 // WPB = waves per workgroup.  Returns false if (lps, wpb) is not instantiated.
 #define MPDATA_WM_LPS(X) X(8) X(16) X(32) X(64)
-template <int LPS, int WPB>
-static void launch_wm_t(const MpdataWmArgs& a, void* stream) {
+template <typename R, int LPS, int WPB>
+static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream) {
   // ntracers == 1: wave = tile in dispatch order, u and w streamed; else the per-XCD tracer walk with
   // u, w kept in L2 (see the kernel)
   // MPDATA_WM_NOSTREAM (tests): run the batch form of the kernel on a single tracer as well
   const bool no_stream = getenv("MPDATA_WM_NOSTREAM") != nullptr;
   if (a.ntracers == 1 && no_stream) {
     const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);
-    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS, WPB, false>), dim3(blocks), dim3(64 * WPB), 0,
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false>), dim3(blocks), dim3(64 * WPB), 0,
                        (hipStream_t)stream, a);
   } else if (a.ntracers == 1) {
     const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);
-    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS, WPB, true>), dim3(blocks), dim3(64 * WPB), 0,
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, true>), dim3(blocks), dim3(64 * WPB), 0,
                        (hipStream_t)stream, a);
   } else {
     const long long per_xcd = ((long long)(a.ntiles + 7) / 8) * a.ntracers;  // waves of one XCD
     const unsigned blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
-    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS, WPB, false>), dim3(blocks), dim3(64 * WPB), 0,
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false>), dim3(blocks), dim3(64 * WPB), 0,
                        (hipStream_t)stream, a);
   }
 }
 bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream) {
   if (wpb != 4) return false;
-#define X(LPS_)                     \
-  if (lps == LPS_) {                \
-    launch_wm_t<LPS_, 4>(a, stream); \
-    return true;                    \
+#define X(LPS_)                             \
+  if (lps == LPS_) {                        \
+    launch_wm_t<double, LPS_, 4>(a, stream); \
+    return true;                            \
+  }
+  MPDATA_WM_LPS(X)
+#undef X
+  return false;
+}
+// fp32 plans: two adjacent instances per lane (8-byte elements = pairs of fp32 values, packed
+// arithmetic); `a` describes the arrays in PAIRS (ncrms / 2 of them)
+bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stream) {
+  if (wpb != 4) return false;
+  MpdataWmArgsT<v2::f32x2> a;
+  a.f = reinterpret_cast<v2::f32x2*>(a8.f);
+  a.u = reinterpret_cast<const v2::f32x2*>(a8.u);
+  a.w = reinterpret_cast<const v2::f32x2*>(a8.w);
+  a.kc = reinterpret_cast<const v2::f32x2*>(a8.kc);
+  a.flux = reinterpret_cast<v2::f32x2*>(a8.flux);
+  a.ntiles = a8.ntiles; a.nx = a8.nx; a.nz = a8.nz; a.ntracers = a8.ntracers;
+  a.tile_elems = a8.tile_elems; a.f_tstride = a8.f_tstride; a.flux_tstride = a8.flux_tstride; a.reverse = a8.reverse;
+#define X(LPS_)                                \
+  if (lps == LPS_) {                           \
+    launch_wm_t<v2::f32x2, LPS_, 4>(a, stream); \
+    return true;                               \
   }
   MPDATA_WM_LPS(X)
 #undef X

@@ -216,3 +216,36 @@ def test_fp32_full_size_config3_sampled_against_oracle(M, oracle, variant):
             assert np.array_equal(f, f_ref) and flux_close(flux, flux_ref)
         else:
             assert max_abs(f, f_ref) < TOL_ABS and max_abs(flux, flux_ref) < TOL_ABS
+
+
+@pytest.mark.parametrize("shape", [(64, 32, 28), (48, 32, 58), (2, 1, 3), (6, 3, 8), (34, 7, 16), (130, 9, 32), (22, 33, 33),
+                                   (10, 6, 64), (258, 31, 28)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_fp32_plan_wavemajor_shapes(M, oracle, shape, variant):
+    """fp32 plans with an even ncrms live in the wave-major layout too (two adjacent instances per
+    lane = 8-byte elements, packed fp32 arithmetic, mpdata_kernel_wm_body.h): EXACT bit-identical in f
+    to the fp32 oracle, FAST within the fp32 tolerances of this file; odd ncrms keeps the reference
+    layout."""
+    var = M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST
+    M.set_variant(var)
+    inp = oracle.make_inputs(*shape, seed=21, dist=1, dtype=F32)
+    f_ref, flux_ref = oracle.advect(inp)
+    p = M.Plan(*shape, 1, dtype=F32)
+    assert p.layout == M.LAYOUT_WAVEMAJOR
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run(); p.sync()
+    f = np.empty_like(inp["f"], order="F"); flux = np.empty_like(inp["flux"], order="F")
+    p.download(f, flux)
+    p.close()
+    nzm = shape[2] - 1
+    if var == M.VARIANT_EXACT:
+        assert np.array_equal(f, f_ref)
+    else:
+        assert np.abs(f.astype(np.float64) - f_ref).max() < 1e-5
+    d = np.abs(flux[:, :nzm].astype(np.float64) - flux_ref[:, :nzm])
+    assert np.all(d <= 2e-5 * np.maximum(1.0, np.abs(flux_ref[:, :nzm])))
+    assert np.array_equal(flux[:, nzm], inp["flux"][:, nzm])
+    if shape[2] <= 32:   # odd ncrms: one instance per lane, reference layout (nz <= 32 only)
+        q = M.Plan(shape[0] + 1, shape[1], shape[2], 1, dtype=F32)
+        assert q.layout == M.LAYOUT_REFERENCE
+        q.close()
