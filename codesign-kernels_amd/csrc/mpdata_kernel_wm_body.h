@@ -56,10 +56,6 @@ using v2::dmax; using v2::dmin; using v2::rabs; using v2::rldexp; using v2::andi
 using v2::upwind; using v2::pp; using v2::pn; using v2::recip_nr; using v2::shift_dn;
 using v2::shift_up; using v2::shift_dn_clamped; using v2::shift_up_clamped; using v2::Window;
 
-#ifndef MPDWM_DEFER_BATCH
-#define MPDWM_DEFER_BATCH 1   // tracer batches defer the odd column's store as well (+3.5 %)
-#endif
-
 template <typename R_, int LPS, int WPB_>
 struct TileWm {
   using R = R_;
@@ -208,9 +204,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(packed));
     return r;
   };
-  // store offset of column c = q - 1 of the step about to run; the march starts at q = -2 (and, when
-  // the odd column's store is deferred, with one empty flush that advances the offset as well)
-  unsigned scur = lvl_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) - (3u + (MPDWM_DEFER_BATCH ? 1u : 0u)) * cstride : OOB;
+  // store offset of column c = q - 1 of the step about to run; the march starts at q = -2, behind one
+  // empty flush of the deferred-store slot, which advances the offset as well
+  unsigned scur = lvl_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) - 4u * cstride : OOB;
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   // pair P of all three arrays into its ring slot.  e*/o*: which columns of the pair exist for
@@ -306,7 +302,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = R(0);
   }
   R S1 = R(0), S3 = R(0);
-  R v_def = R(0);   // STREAM: the deferred store of a pair's odd column
+  R v_def = R(0);   // the deferred store of a pair's odd column
   bool act_def = false;
   int c_def = 0;
 
@@ -465,10 +461,10 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
       R v = S.F1[C3];  // halo columns keep the first-pass value (:557)
       if (FULL || (n >= 1 && n <= nx))
         v = dmax(R(0), S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
-      // STREAM: the odd column's store waits until the next pair has been waited for -- the
-      // counted wait must see every store issued after the pair's DMA complete, and a
-      // (slow, streaming) store issued right before it would stall it for a store round trip
-      if constexpr ((STREAM || MPDWM_DEFER_BATCH) && decltype(h_tag)::value == 1) {
+      // the odd column's store waits until the next pair has been waited for: the counted wait
+      // must see every store issued after the pair's DMA complete, and a store issued right
+      // before it would stall it for a store round trip (+1 % one tracer, +3.5 % tracer batches)
+      if constexpr (decltype(h_tag)::value == 1) {
         v_def = v; act_def = FULL || act; c_def = max(n + 2, 0);
       } else {
         st_col(FULL || act, max(n + 2, 0), v, std::integral_constant<int, 0>{});
@@ -504,7 +500,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 // issued in between as well -- vmcnt(10) / vmcnt(5) -- is a race: a store may be acknowledged
 // before an older load has landed, and the count then drops below the mark with a DMA of the
 // pair still in flight; seen as sporadic wrong columns with default-policy stores.)
-#define MPDWM_FLUSH_DEFERRED if constexpr (STREAM || MPDWM_DEFER_BATCH) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
+#define MPDWM_FLUSH_DEFERRED st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
 #define MPDWM_PAIR(PHA, PHB, SL, TAG, q, DMA)           \
   if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
   else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  \
@@ -534,7 +530,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #undef MPDWM_PAIR
 #undef MPDWM_FLUSH_DEFERRED
 
-  if constexpr (STREAM || MPDWM_DEFER_BATCH) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
+  st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
   if (lvl_ok) flux[pos] = S1 + S3;  // :541-547, :624
 }
 
