@@ -29,8 +29,9 @@
 //     registers, SLP*nzm*8 contiguous bytes per wave instruction);
 //   * columns arrive by LDS-DMA, two 16-byte-per-lane instructions per array and column PAIR
 //     (main parts, remainders; lanes 0-31 the even column, 32-63 the odd one), into a per-wave
-//     ring of 3 pairs; one counted s_waitcnt vmcnt per pair is the only synchronisation, two
-//     pairs stay in flight;
+//     ring of 3 pairs; one counted s_waitcnt vmcnt per pair is the only synchronisation; a pair's
+//     slot is refilled as soon as its two columns have been read (nobody else reads it: the ring
+//     is private to the wave), so three pairs are in flight while one is being worked on;
 //   * the LDS ring only serves as a prefetch buffer that costs no VGPRs and as the source of
 //     the raw inputs of the vertical neighbours (kb / kc clamps in the read address).
 // mpdata_layout.hip converts between this layout and the reference's (upload / download /
@@ -270,7 +271,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   };
 
   // ---- prologue: zero the ring (the never-fetched tails of the column blocks supply w = 0 of
-  //      the ghost level), then pairs 0 and 1 into flight, each behind two dropped column stores so
+  //      the ghost level), then pairs 0, 1, 2 into flight, each behind two dropped column stores so
   //      that the counted wait of the first pairs sees the steady-state op pattern
 #pragma unroll
 #ifdef MPDWM_ABL_NODMA  // timing ablation: arithmetic on (non-zero, finite) stand-in data
@@ -280,7 +281,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int P = 0; P < T::NS - 1; ++P) {
+  for (int P = 0; P < T::NS; ++P) {
     st_col(false, 0, R(0), std::integral_constant<int, 1>{});
     st_col(false, 0, R(0), std::integral_constant<int, 1>{});
     dma_pair(P);
@@ -488,11 +489,11 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   //   fill (q = -2 .. 3) and drain trips: wave-uniform conditions; steps beyond q = nx+3 do nothing;
   //   steady-state trips (4 <= q, q+5 <= nx): every stage active, no conditions.
   const int q_last = nx + 3;
-  // per pair: wait for it (STREAM: 6 DMA instructions, else 3, were issued since its own), two column steps,
-  // fetch pair P+2 into the slot of pair P-1
-  auto dma_p = [&](const int q) __attribute__((always_inline)) { dma_pair(((q + 1) >> 1) + 2); };  // q: odd column of the pair
+  // per pair: wait for it (two newer pairs: STREAM 2 x 6 DMA instructions, else 2 x 3), two column steps,
+  // fetch pair P+3 into the slot just read
+  auto dma_p = [&](const int q) __attribute__((always_inline)) { dma_pair(((q + 1) >> 1) + 3); };  // q: odd column of the pair
   auto dma_f = [&](const int q) __attribute__((always_inline)) {
-    const int P = ((q + 1) >> 1) + 2;
+    const int P = ((q + 1) >> 1) + 3;
     if (2 * P + 1 <= nx + 4) dma_pair_full(P); else dma_pair(P);
   };
 // The counted waits only rely on LOADS returning in issue order: "at most as many operations
@@ -502,8 +503,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 // pair still in flight; seen as sporadic wrong columns with default-policy stores.)
 #define MPDWM_FLUSH_DEFERRED st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
 #define MPDWM_PAIR(PHA, PHB, SL, TAG, q, DMA)           \
-  if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
-  else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  \
+  if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  \
   MPDWM_FLUSH_DEFERRED                                  \
   step(PHA{}, SL{}, I0{}, TAG{}, (q));                  \
   asm volatile("" ::: "memory");                        \
