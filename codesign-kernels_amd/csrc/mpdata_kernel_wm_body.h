@@ -255,7 +255,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   auto st_col = [&](const bool act, const int c, const R v, auto ahead_tag) __attribute__((always_inline)) {
     constexpr int AHEAD = decltype(ahead_tag)::value;
 #ifdef MPD2_ABL_NOMEM  // timing ablation only (wrong results)
-    if (v != 1.2345e300) return;
+    if (__builtin_bit_cast(double, v) != 1.2345e300) return;
 #endif
     const v2::u32x2 b = __builtin_bit_cast(v2::u32x2, v);
     if constexpr (STREAM) {
