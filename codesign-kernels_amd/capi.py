@@ -94,6 +94,8 @@ def lib():
         L.mpdata_plan_ngpus.argtypes = [vp]
         L.mpdata_plan_shard.restype = ci
         L.mpdata_plan_shard.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        L.mpdata_plan_shard_plan.restype = vp
+        L.mpdata_plan_shard_plan.argtypes = [vp, ci]
         L.mpdata_plan_transfer_stats.restype = ci
         L.mpdata_plan_transfer_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                                  ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(ci)]

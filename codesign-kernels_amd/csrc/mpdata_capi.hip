@@ -788,6 +788,11 @@ int mpdata_plan_shard(const mpdata_plan* p, int g, int* device, int64_t* sl0, in
   if (nloc) *nloc = p->ncrms;
   return 0;
 }
+mpdata_plan* mpdata_plan_shard_plan(mpdata_plan* p, int g) {
+  if (!p) return nullptr;
+  if (p->multi) return mpdata_multi_sub(p->multi, g);
+  return g == 0 ? p : nullptr;
+}
 int mpdata_plan_transfer_stats(const mpdata_plan* p, double* scatter_s, double* gather_s, int64_t* scatter_bytes_per_peer,
                                int64_t* gather_bytes_per_peer, int* transport) {
   if (!p || !p->multi) return set_err(MPDATA_EINVAL, "not a multi-GPU plan");

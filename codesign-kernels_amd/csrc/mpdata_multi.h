@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 struct mpdata_multi;
+struct mpdata_plan;
 
 // error text of the library (thread-local, returned by mpdata_last_error)
 __attribute__((visibility("hidden"))) int mpdata_internal_set_err(int code, const char* fmt, ...);
@@ -21,5 +22,6 @@ __attribute__((visibility("hidden"))) int mpdata_multi_info(const mpdata_multi* 
 __attribute__((visibility("hidden"))) void mpdata_multi_stats(const mpdata_multi* m, double* scatter_s, double* gather_s,
                                                               int64_t* scatter_bytes_peer, int64_t* gather_bytes_peer, int* xfer);
 __attribute__((visibility("hidden"))) int mpdata_multi_ngpus(const mpdata_multi* m);
+__attribute__((visibility("hidden"))) struct mpdata_plan* mpdata_multi_sub(const mpdata_multi* m, int g);
 __attribute__((visibility("hidden"))) int mpdata_multi_destroy(mpdata_multi* m);
 #endif

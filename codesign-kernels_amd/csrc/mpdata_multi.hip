@@ -398,6 +398,7 @@ void mpdata_multi_stats(const mpdata_multi* m, double* scatter_s, double* gather
 }
 
 int mpdata_multi_ngpus(const mpdata_multi* m) { return m->ngpus; }
+mpdata_plan* mpdata_multi_sub(const mpdata_multi* m, int g) { return (g >= 0 && g < m->ngpus) ? m->sub[g] : nullptr; }
 
 int mpdata_multi_destroy(mpdata_multi* m) {
   if (!m) return 0;

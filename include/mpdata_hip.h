@@ -143,6 +143,9 @@ int mpdata_plan_create_multi_devices(int64_t ncrms, int nx, int nz, int ntracers
 void mpdata_shard_range(int64_t ncrms, int ngpus, int g, int64_t* sl0, int64_t* nloc); /* block of GPU g */
 int mpdata_plan_ngpus(const mpdata_plan* plan);
 int mpdata_plan_shard(const mpdata_plan* plan, int g, int* device, int64_t* sl0, int64_t* nloc);
+/* the single-device plan of GPU g (owned by the multi-GPU plan: do not destroy): for callers whose
+ * shard already lives on that device -- mpdata_plan_import_device / _export_device on it */
+mpdata_plan* mpdata_plan_shard_plan(mpdata_plan* plan, int g);
 /* wall seconds and bytes per peer link of the last upload (scatter) / download (gather);
  * transport: 0 rccl, 1 p2p, 2 direct */
 int mpdata_plan_transfer_stats(const mpdata_plan* plan, double* scatter_s, double* gather_s,
