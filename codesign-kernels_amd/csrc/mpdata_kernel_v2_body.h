@@ -150,18 +150,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0,
                                            (int)(unsigned)(bytes > lim ? lim : bytes), 0x00020000);
 }
+template <int AUX = MPD2_ST_AUX>
 __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
 #ifdef MPD2_ABL_NOMEM  // timing ablation only (wrong results)
   if (v != 1.2345e300) return;
 #endif
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, MPD2_ST_AUX);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x2 v) {
 #ifdef MPD2_ABL_NOMEM
   if (v.x != 1.2345e30f) return;
 #endif
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
 #ifdef MPD2_ABL_NOMEM
   if (v != 1.2345e30f) return;
@@ -295,9 +298,14 @@ struct Window {
 // column offset, a 32-bit scalar, needs ncrms * (nx+6) * sizeof(R) < 4 GiB).  Otherwise one
 // descriptor per array serves all waves (7 descriptors instead of 3 cost 2 % through scalar
 // register pressure, hence the two instantiations).
-template <typename R, int LPS, int G, bool BIG>
+// NT (fp64, one tracer per launch): row fetches and row stores with the streaming cache policy.
+// Every 128-byte row segment is touched by exactly one fetch and one store instruction, so
+// nothing is lost by not keeping it, and the pair of hints buys 1-3 % (either alone: nothing).
+template <typename R, int LPS, int G, bool BIG, bool NT = false>
 __global__ void __launch_bounds__(G * LPS, (TileV2<R, LPS, G>::MIN_WAVES))
 mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
+  constexpr int LD_AUX = NT ? 2 : MPD2_LD_AUX;
+  constexpr int ST_AUX = (NT && std::is_same<R, double>::value) ? 2 : (std::is_same<R, double>::value ? MPD2_ST_AUX : 0);
   using T = TileV2<R, LPS, G>;
   constexpr int RS = T::RS, SLP = T::SLP, RPI = T::RPI;
   constexpr int RB = (int)sizeof(R);  // bytes per element
@@ -452,9 +460,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
 #pragma unroll
     for (int it = 0; it < T::NIT; ++it) {
       R* d = slot + jd[it] * T::EPI;  // 256 bytes per instruction
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdf[it], (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, MPD2_LD_AUX);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdu[it], (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, MPD2_LD_AUX);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdw[it], (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, MPD2_LD_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdf[it], (lds_ptr_t)(d), 4, (int)vdf[it], (int)cf, 0, LD_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdu[it], (lds_ptr_t)(d + T::ARR), 4, (int)vdu[it], (int)cu, 0, LD_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdw[it], (lds_ptr_t)(d + 2 * T::ARR), 4, (int)vdw[it], (int)cw, 0, LD_AUX);
     }
   };
 
@@ -521,7 +529,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
 #ifdef MPD2_ABL_NOCOMPUTE  // timing ablation only: data movement without the arithmetic
     if (q - 3 >= -1 && q - 3 <= nx + 2 && lvl_ok) out_slot0[(q & 1) * T::OUT_SLOT + (k - 1) * RS + sl_l] = f0q + uq + wq;
     asm volatile("" ::: "memory");
-    st_row(rsf, (q - 4 >= -1 && q - 4 <= nx + 2) ? tf : OOB, colb * (unsigned)max(q - 4 + 2, 0),
+    st_row<ST_AUX>(rsf, (q - 4 >= -1 && q - 4 <= nx + 2) ? tf : OOB, colb * (unsigned)max(q - 4 + 2, 0),
            out_slot0[((q - 1) & 1) * T::OUT_SLOT + t_lds]);
     dma_col(q + T::NSLOT - 1);
     return;
@@ -685,7 +693,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
     asm volatile("" ::: "memory");
     {
       const bool act = q - 4 >= -1 && q - 4 <= nx + 2;
-      st_row(rsf, (FULL || act) ? tf : OOB, colb * (unsigned)max(q - 4 + 2, 0),
+      st_row<ST_AUX>(rsf, (FULL || act) ? tf : OOB, colb * (unsigned)max(q - 4 + 2, 0),
              out_slot0[((q - 1) & 1) * T::OUT_SLOT + t_lds]);
     }
     dma_col(q + T::NSLOT - 1);
@@ -710,7 +718,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   // counted wait of the first steps sees the steady-state op pattern
 #pragma unroll
   for (int c = q_first; c < q_first + T::NSLOT - 1; ++c) {
-    st_row(rsf, OOB, 0, R(0));
+    st_row<ST_AUX>(rsf, OOB, 0, R(0));
     dma_col(c);
   }
 
@@ -758,9 +766,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      st_row(rsf, tf, colb * (unsigned)(nx + 2), tA[t_lds]);
-      st_row(rsf, tf, colb * (unsigned)(nx + 3), tB[t_lds]);
-      st_row(rsf, tf, colb * (unsigned)(nx + 4), tC[t_lds]);
+      st_row<ST_AUX>(rsf, tf, colb * (unsigned)(nx + 2), tA[t_lds]);
+      st_row<ST_AUX>(rsf, tf, colb * (unsigned)(nx + 3), tB[t_lds]);
+      st_row<ST_AUX>(rsf, tf, colb * (unsigned)(nx + 4), tC[t_lds]);
     };
     const int rem = nx + 4 - q;  // 0, 1 or 2 single steps left
     if (rem == 0) {

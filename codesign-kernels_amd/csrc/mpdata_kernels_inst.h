@@ -64,6 +64,8 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
   const bool big = (double)a.ncrms * (a.nx + 6) * a.nz * (double)sizeof(R) >= 4294967000.0;
   if (big)
     hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, true>), grid, block, 0, (hipStream_t)stream, b);
+  else if (std::is_same<R, double>::value && G == 16 && ntracers == 1)   // one tracer: streaming rows (+1..3 %)
+    hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, false, true>), grid, block, 0, (hipStream_t)stream, b);
   else
     hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, false>), grid, block, 0, (hipStream_t)stream, b);
 }
