@@ -103,3 +103,38 @@ def test_multi_plan_argument_errors(mpdata):
         M.Plan(64, 32, 28, 1, devices=[0, 99])
     with pytest.raises(M.MpdataError):
         M.Plan(2, 32, 28, 1, devices=[0, 0, 0])     # fewer instances than GPUs
+
+
+@pytest.mark.gpu
+def test_shard_plans_are_ordinary_plans(mpdata, oracle, monkeypatch):
+    """mpdata_plan_shard_plan: the per-GPU plan of a multi-GPU plan takes device-side import /
+    export of its block (a caller whose shards already live on the devices)."""
+    import ctypes
+    import torch
+    from util import to_dev, to_host
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    monkeypatch.setenv("MPDATA_MULTI_XFER", "direct")
+    ncrms, nx, nz = 90, 12, 9
+    inp = oracle.make_inputs(ncrms, nx, nz, seed=4, dist=1)
+    p = M.Plan(ncrms, nx, nz, 1, devices=[0, 0])
+    L = M.lib()
+    f_ref, flux_ref = oracle.advect(inp, nthreads=2)
+    outs = []
+    for g, (dev, sl0, nloc) in enumerate(p.shards()):
+        sub = L.mpdata_plan_shard_plan(p._p, g)
+        assert sub
+        blk = {k: to_dev(np.asfortranarray(v[sl0:sl0 + nloc])) for k, v in inp.items()}
+        args = [ctypes.c_void_p(blk[k].data_ptr()) for k in ("f", "u", "w", "rho", "rhow", "adz", "flux")]
+        assert L.mpdata_plan_import_device(ctypes.c_void_p(sub), *args, 0, 1) == 0
+        outs.append((sub, blk, sl0, nloc))
+    p.run(); p.sync()
+    for sub, blk, sl0, nloc in outs:
+        assert L.mpdata_plan_export_device(ctypes.c_void_p(sub), ctypes.c_void_p(blk["f"].data_ptr()),
+                                           ctypes.c_void_p(blk["flux"].data_ptr()), 0, 1) == 0
+    p.sync()
+    torch.cuda.synchronize()
+    for sub, blk, sl0, nloc in outs:
+        assert np.array_equal(to_host(blk["f"]), f_ref[sl0:sl0 + nloc])
+    assert L.mpdata_plan_shard_plan(p._p, 5) is None
+    p.close()
