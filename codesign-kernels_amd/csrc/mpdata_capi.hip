@@ -639,14 +639,14 @@ int mpdata_plan_export_device(mpdata_plan* p, void* f, void* flux, int first_tra
 
 int mpdata_plan_run_tracers(mpdata_plan* p, int first, int count) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
-  if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run before mpdata_plan_upload");
   int rc = tracer_range(p, first, count);
   if (rc) return rc;
-  if (p->multi) {
+  if (p->multi) {   // (the per-GPU plans check their own state: they may have been filled directly)
     rc = mpdata_multi_run(p->multi, first, count);
     if (!rc) p->ran = true;
     return rc;
   }
+  if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run before mpdata_plan_upload");
   DevGuard g(p->device);
   HIP_TRY(hipEventRecord(p->ev0, p->stream));
   if (p->layout == MPDATA_LAYOUT_WAVEMAJOR) {

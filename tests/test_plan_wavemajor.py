@@ -241,3 +241,23 @@ def test_plan_arrays_larger_than_4GiB(M, oracle):
     offsets relative to per-wave descriptor bases, so array size does not matter)."""
     _full_size_check(M, oracle, M.VARIANT_EXACT, 600000, 32, 28, 1,
                      ((0, 40), (123456 + 3, 37), (299990, 50), (600000 - 21, 21)))
+
+
+def test_random_shapes_both_forms(M, oracle, monkeypatch):
+    """40 seeded random shapes (ncrms 1..300, nx 1..70, nz 3..64), alternately through the streaming
+    form and the batch form of the kernel, EXACT: f bit-identical to the oracle."""
+    rng = np.random.default_rng(20261004)
+    M.set_variant(M.VARIANT_EXACT)
+    for it in range(40):
+        ncrms = int(rng.integers(1, 301))
+        nx = int(rng.integers(1, 71))
+        nz = int(rng.choice([rng.integers(3, 9), rng.integers(9, 17), rng.integers(17, 33), rng.integers(33, 65)]))
+        if it % 2:
+            monkeypatch.setenv("MPDATA_WM_NOSTREAM", "1")
+        else:
+            monkeypatch.delenv("MPDATA_WM_NOSTREAM", raising=False)
+        inp = oracle.make_inputs(ncrms, nx, nz, seed=1000 + it, dist=3 if it % 3 else 1)
+        f, flux = run_plan_host(M, inp)
+        f_ref, flux_ref = oracle.advect(inp, nthreads=4)
+        assert np.array_equal(f, f_ref), (ncrms, nx, nz, it, max_abs(f, f_ref))
+        assert flux_close(flux, flux_ref), (ncrms, nx, nz, it)
