@@ -604,14 +604,22 @@ def bench_scatter_gather(M, torch, dist, world, rank, dev, n_loc, nx, nz):
     ns = n_loc * world
     names = ("adz", "f", "u", "w", "rho", "rhow", "flux")
     sh = M.shapes(ns, nx, nz)
+    full, ok = None, 1
     if rank == 0:
-        full = {k: torch.empty(sh[k], dtype=torch.float64, device=dev) for k in names}
-        for k in names:
-            M.fill_synthetic(full[k], k, 100, 1)
-        arg = full
-    else:
-        full = None
-        arg = {k: sh[k][:-1] for k in names}
+        try:
+            full = {k: torch.empty(sh[k], dtype=torch.float64, device=dev) for k in names}
+            for k in names:
+                M.fill_synthetic(full[k], k, 100, 1)
+        except Exception:   # (e.g. out of memory on the root): every rank must skip the exchange
+            full, ok = None, 0
+            torch.cuda.empty_cache()
+    # all ranks agree before the first send/recv: a rank that raised here would leave the others
+    # waiting in the exchange for ever
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        raise RuntimeError("root could not allocate the global problem for the scatter/gather measurement")
+    arg = full if rank == 0 else {k: sh[k][:-1] for k in names}
     torch.cuda.synchronize(); dist.barrier()
     t0 = time.perf_counter()
     mine = M.scatter_inputs(arg, ns, src=0, device=dev)

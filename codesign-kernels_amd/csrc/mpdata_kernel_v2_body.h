@@ -369,10 +369,17 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   // exponent step on dd*(...) (exact scaling, bit-identical)
   const int dd_exp = (k == 1 || k == nzm) ? 1 : 0;
 #ifdef MPDATA_FAST_DIV
-  const R KU = rldexp(R(0.03125) * IRHO * IADZ, dd_exp);
+  // FAST carries the second-pass fluxes DOUBLED (andiff's factor 0.5 is not applied: one
+  // multiplication fewer per flux) and the limiter ratios HALVED (doubled denominators, clamp
+  // at 0.5), so the limited fluxes come out unscaled; every scaling is by a power of two, i.e.
+  // the results are bit-identical to the unscaled evaluation
+  const R EPS_D = eps + eps, LIM = R(0.5);
+  const R KU = rldexp(R(0.03125) * IRHO * IADZ, dd_exp + 1);
   // www(:,:,:,1) = 0 (:586) lives in the constant: at k = 1 the advective part of W2 is an
   // exact zero already (kb = k, f - f(kb) = 0), a zero KW removes the cross part
-  const R KW = (k == 1) ? R(0) : R(0.03125) * IRHO;
+  const R KW = (k == 1) ? R(0) : R(0.0625) * IRHO;
+#else
+  const R EPS_D = eps, LIM = R(1);
 #endif
   const bool k_is_1 = k == 1;
   const bool k_ge_nzm = k >= nzm;
@@ -601,7 +608,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
         const R u1 = S.UR[C1];
         const R t1 = rabs(u1) - (u1 * u1) * IRHO;
         const R x4 = S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1;
-        U2_1 = R(0.5) * (t1 * (f1_1 - S.F1[C2])) - KU * ((u1 * S.SW[C1]) * x4);
+        U2_1 = t1 * (f1_1 - S.F1[C2]) - KU * ((u1 * S.SW[C1]) * x4);   // = 2 x (:571-573)
 #else
         const R ad = andiff(S.F1[C2], f1_1, S.UR[C1], IRHO);
         const R x = rldexp(IADZ * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1), dd_exp);
@@ -616,7 +623,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
           const R w2 = S.WR[C2];
           const R t1 = rabs(w2) - (w2 * w2) * IRHOW;
           const R x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
-          W2_2 = R(0.5) * (t1 * (S.F1[C2] - S.F1D[C2])) - KW * ((w2 * S.SU[C2]) * x4);  // k = 1: 0
+          W2_2 = t1 * (S.F1[C2] - S.F1D[C2]) - KW * ((w2 * S.SU[C2]) * x4);  // = 2 x (:580-582); k = 1: 0
 #else
           const R ad = andiff(S.F1D[C2], S.F1[C2], S.WR[C2], IRHOW);
           const R x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
@@ -631,10 +638,8 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
         // :606-609
         W2p = pp(W2_2);
         W2n = pn(W2_2);
-        const R num_mx = RHO * (mx1 - S.F1[C2]);
-        const R den_mx = U2n_1 + S.U2P[C2] + IADZ * (pn(W2u) + W2p) + eps;
-        const R num_mn = RHO * (S.F1[C2] - mn1);
-        const R den_mn = U2p_1 + S.U2N[C2] + IADZ * (pp(W2u) + W2n) + eps;
+        const R den_mx = U2n_1 + S.U2P[C2] + IADZ * (pn(W2u) + W2p) + EPS_D;
+        const R den_mn = U2p_1 + S.U2N[C2] + IADZ * (pp(W2u) + W2n) + EPS_D;
 #ifdef MPDATA_FAST_DIV
         // FAST: one reciprocal for both ratios, r = 1/(den_mx*den_mn) (both >= eps = 1e-10,
         // finite), two Newton steps, then a/b = a * (other denominator) * r.
@@ -642,17 +647,17 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
         //  cancels: on the reference-raw input law it costs 4 digits of the rel-L1 agreement.)
         {
           const R dd2 = den_mx * den_mn;
-          const R r = recip_nr(dd2);
-          MXN_2 = num_mx * (den_mn * r);
-          MNN_2 = num_mn * (den_mx * r);
+          const R r = RHO * recip_nr(dd2);   // (rho once for both ratios)
+          MXN_2 = (mx1 - S.F1[C2]) * (den_mn * r);
+          MNN_2 = (S.F1[C2] - mn1) * (den_mx * r);
         }
 #else
-        MXN_2 = num_mx / den_mx;
-        MNN_2 = num_mn / den_mn;
+        MXN_2 = RHO * (mx1 - S.F1[C2]) / den_mx;
+        MNN_2 = RHO * (S.F1[C2] - mn1) / den_mn;
 #endif
         // the ratios are only ever used as min(1, ratio, ...) (:618, :623): keep them clamped
-        MXN_2 = dmin(R(1), MXN_2);
-        MNN_2 = dmin(R(1), MNN_2);
+        MXN_2 = dmin(LIM, MXN_2);
+        MNN_2 = dmin(LIM, MNN_2);
       }
     }
     S.U2P[C1] = U2p_1;
