@@ -272,7 +272,24 @@ PREWARM_MS = 60.0  # --prewarm-ms
 # VALU instructions one wave executes per call at nx=32, nz=28 (rocprofv3 SQ_INSTS_VALU / SQ_WAVES,
 # profiles/r02_pmc_summary.json) and the measured fp64 VALU issue peak of the chip
 # (tools/valu_rate.hip: 33e12 lane-ops/s = 515.6e9 wave-instructions/s)
-VALU_PER_WAVE_NX32_NZ28 = {"fast": 4289.0, "exact": None}
+def valu_instructions_per_launch(variant, n_loc, nx, nz, ntr):
+    """VALU wave-instructions of one plan run of this shape, from the SQ counters of the recorded
+    profile (profiles/*_pmc_summary.json: t25_wavemajor.valu_instructions_per_launch); None if the
+    shape was not profiled."""
+    if variant != "fast" or (n_loc, nx, nz, ntr) != (65536, 32, 28, 25):
+        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                v = json.load(fh).get("t25_wavemajor", {}).get("valu_instructions_per_launch")
+            if v:
+                return float(v), os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    return None
+
+
 VALU_PEAK_WAVE_INSTR_PER_S = 33.0e12 / 64.0
 
 
@@ -487,13 +504,13 @@ def main():
             rb = roofline_block(ab, kms2, {"traffic": tr2, "traffic_source": None if tr2 is None else
                                            "profiles/hbm_traffic.json[%s] (recorded profile, not this run)" % key})
             rb["hbm_frac"] = rb["frac"]
-            vpw = VALU_PER_WAVE_NX32_NZ28.get(args.variant) if (nx, nz) == (32, 28) and not f32 else None
-            if vpw:   # second ceiling (SURVEY.md 7 hard part 3): fp64 VALU issue
-                waves = -(-n_loc // 2) * bt
-                t_valu = waves * vpw / VALU_PEAK_WAVE_INSTR_PER_S
+            vi = None if f32 else valu_instructions_per_launch(args.variant, n_loc, nx, nz, bt)
+            if vi:   # second ceiling (SURVEY.md 7 hard part 3): fp64 VALU issue
+                t_valu = vi[0] / VALU_PEAK_WAVE_INSTR_PER_S
                 rb["valu_frac"] = t_valu / (ka * 1e-3)
-                rb["valu_note"] = "VALU instructions per launch (profiles/r02_pmc_summary.json) / measured fp64 VALU " \
-                                  "issue peak (tools/valu_rate.hip, 33e12 lane-ops/s) / kernel time"
+                rb["valu_note"] = "VALU instructions per launch (%s, SQ counters of the builder's box) / measured fp64 " \
+                                  "VALU issue peak (tools/valu_rate.hip: 33e12 lane-ops/s, at the 2.0 GHz that " \
+                                  "microbenchmark sustains; this kernel runs at 1.7-1.85 GHz, power-limited) / kernel time" % vi[1]
             result["tracer_batched"] = {
                 "workload": f"BASELINE.json configs[{3 if world == 1 else 4}]: ncrms={n_loc}/GPU (global {n_glob}), "
                             f"{bt} tracers sharing u,w,rho,rhow,adz, plan API",

@@ -608,7 +608,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
         const R u1 = S.UR[C1];
         const R t1 = rabs(u1) - (u1 * u1) * IRHO;
         const R x4 = S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1;
-        U2_1 = t1 * (f1_1 - S.F1[C2]) - KU * ((u1 * S.SW[C1]) * x4);   // = 2 x (:571-573)
+        U2_1 = t1 * (f1_1 - S.F1[C2]) - (KU * (u1 * S.SW[C1])) * x4;   // = 2 x (:571-573)
 #else
         const R ad = andiff(S.F1[C2], f1_1, S.UR[C1], IRHO);
         const R x = rldexp(IADZ * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1), dd_exp);
@@ -623,7 +623,7 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
           const R w2 = S.WR[C2];
           const R t1 = rabs(w2) - (w2 * w2) * IRHOW;
           const R x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
-          W2_2 = t1 * (S.F1[C2] - S.F1D[C2]) - KW * ((w2 * S.SU[C2]) * x4);  // = 2 x (:580-582); k = 1: 0
+          W2_2 = t1 * (S.F1[C2] - S.F1D[C2]) - (KW * (w2 * S.SU[C2])) * x4;  // = 2 x (:580-582); k = 1: 0
 #else
           const R ad = andiff(S.F1D[C2], S.F1[C2], S.WR[C2], IRHOW);
           const R x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];

@@ -57,7 +57,59 @@ using v2::dmax; using v2::dmin; using v2::rabs; using v2::rldexp; using v2::andi
 using v2::upwind; using v2::pp; using v2::pn; using v2::recip_nr; using v2::shift_dn;
 using v2::shift_up; using v2::shift_dn_clamped; using v2::shift_up_clamped; using v2::Window;
 
-template <typename R_, int LPS, int WPB_>
+// Two tracers per wave (tracer batches): the tracer-dependent quantities of the column step are
+// PAIRS, one member per tracer, and every statement on them expands member by member -- the two
+// tracers' (independent) instruction chains come out interleaved, which is what keeps the fp64
+// pipe busy with only two waves per SIMD.  u, w and everything formed from them alone stay
+// scalars of type R: fetched / computed once for both tracers.
+template <typename R>
+struct Pair {
+  R a, b;
+  __device__ __forceinline__ Pair() {}
+  __device__ __forceinline__ explicit Pair(R x) : a(x), b(x) {}
+  __device__ __forceinline__ Pair(R x, R y) : a(x), b(y) {}
+};
+#define MPDWM_PAIR_OP(OP)                                                                                                  \
+  template <typename R> __device__ __forceinline__ Pair<R> operator OP(Pair<R> x, Pair<R> y) { return {x.a OP y.a, x.b OP y.b}; } \
+  template <typename R> __device__ __forceinline__ Pair<R> operator OP(Pair<R> x, R y) { return {x.a OP y, x.b OP y}; }           \
+  template <typename R> __device__ __forceinline__ Pair<R> operator OP(R x, Pair<R> y) { return {x OP y.a, x OP y.b}; }
+MPDWM_PAIR_OP(+) MPDWM_PAIR_OP(-) MPDWM_PAIR_OP(*) MPDWM_PAIR_OP(/)
+#undef MPDWM_PAIR_OP
+template <typename R> __device__ __forceinline__ Pair<R> operator-(Pair<R> x) { return {-x.a, -x.b}; }
+template <typename R> __device__ __forceinline__ Pair<R> dmax(Pair<R> x, Pair<R> y) { return {dmax(x.a, y.a), dmax(x.b, y.b)}; }
+template <typename R> __device__ __forceinline__ Pair<R> dmin(Pair<R> x, Pair<R> y) { return {dmin(x.a, y.a), dmin(x.b, y.b)}; }
+template <typename R> __device__ __forceinline__ Pair<R> dmax(R x, Pair<R> y) { return {dmax(x, y.a), dmax(x, y.b)}; }
+template <typename R> __device__ __forceinline__ Pair<R> dmin(R x, Pair<R> y) { return {dmin(x, y.a), dmin(x, y.b)}; }
+template <typename R> __device__ __forceinline__ Pair<R> rldexp(Pair<R> x, int e) { return {rldexp(x.a, e), rldexp(x.b, e)}; }
+template <typename R> __device__ __forceinline__ Pair<R> recip_nr(Pair<R> x) { return {recip_nr(x.a), recip_nr(x.b)}; }
+template <typename R> __device__ __forceinline__ Pair<R> shift_dn(Pair<R> x) { return {shift_dn(x.a), shift_dn(x.b)}; }
+template <typename R> __device__ __forceinline__ Pair<R> shift_up(Pair<R> x) { return {shift_up(x.a), shift_up(x.b)}; }
+template <typename R> __device__ __forceinline__ Pair<R> shift_dn_clamped(Pair<R> x, unsigned long long own) {
+  return {shift_dn_clamped(x.a, own), shift_dn_clamped(x.b, own)};
+}
+template <typename R> __device__ __forceinline__ Pair<R> shift_up_clamped(Pair<R> x, unsigned long long own) {
+  return {shift_up_clamped(x.a, own), shift_up_clamped(x.b, own)};
+}
+// upwind flux with a shared velocity (:532, :537): a * (a >= 0 ? x : y) per tracer
+template <typename R> __device__ __forceinline__ Pair<R> upwind(R a, Pair<R> x, Pair<R> y) {
+  return {a * v2::sel_ge0(a, x.a, y.a), a * v2::sel_ge0(a, x.b, y.b)};
+}
+// statement functions :500-501 with tracer-independent velocity arguments (same operation order
+// as v2::andiff / v2::across; the velocity factors are common to both tracers)
+template <typename X, typename R> __device__ __forceinline__ X andiff_s(X x1, X x2, R a, R b) {
+  return ((rabs(a) - a * a * b) * R(0.5)) * (x2 - x1);
+}
+template <typename X, typename R> __device__ __forceinline__ X across_s(X x1, R a1, R a2) {
+  return ((R(0.03125) * a1) * a2) * x1;
+}
+template <typename R> __device__ __forceinline__ R sel(bool c, R x, R y) { return c ? x : y; }
+template <typename R> __device__ __forceinline__ Pair<R> sel(bool c, Pair<R> x, Pair<R> y) { return {c ? x.a : y.a, c ? x.b : y.b}; }
+template <typename R> __device__ __forceinline__ R first(R x) { return x; }
+template <typename R> __device__ __forceinline__ R second(R x) { return x; }
+template <typename R> __device__ __forceinline__ R first(Pair<R> x) { return x.a; }
+template <typename R> __device__ __forceinline__ R second(Pair<R> x) { return x.b; }
+
+template <typename R_, int LPS, int WPB_, int TPW_ = 1>
 struct TileWm {
   using R = R_;
   static constexpr int SLP = 64 / LPS;          // instances per wave = per tile
@@ -67,10 +119,13 @@ struct TileWm {
   static constexpr int NS = 3;                  // ring: column pairs P .. P+2
   static constexpr int HALF = 64;               // elements between the two columns of a pair in LDS
   static constexpr int ARR = 128;               // elements of one array block of a slot (1 KiB)
-  static constexpr int SLOT = 3 * ARR;          // f, u, w
+  static constexpr int TPW = TPW_;              // tracers per wave (tracer batches: 1 or 2)
+  static constexpr int UO = TPW_ * ARR, WO = (TPW_ + 1) * ARR;   // a slot: f of every tracer of the wave, u, w
+  static constexpr int SLOT = (2 + TPW_) * ARR;
   static constexpr int LDS_ELEMS = WPB_ * NS * SLOT;
   // 128 VGPRs; one instance per wave (LPS = 64) carries the ghost-level select of w and gets 168
-  static constexpr int MIN_WAVES = LPS == 64 ? 3 : 4;
+  // (two tracers per wave: twice the tracer state, 256 VGPRs, 2 waves per SIMD)
+  static constexpr int MIN_WAVES = TPW_ == 2 ? 2 : (LPS == 64 ? 3 : 4);
   static_assert(sizeof(R_) == 8, "8-byte elements (double, or two fp32 instances per lane)");
 };
 
@@ -79,10 +134,16 @@ struct TileWm {
 // policy -- two instructions per array and pair, two per column store.  !STREAM (tracer batches:
 // VALU-bound, u and w are re-read from L2 by the other tracers of the tile): ONE instruction per
 // array and pair / per column store, default policy, every lane addressing its own part.
-template <typename R, int LPS, int WPB, bool STREAM>
-__global__ void __launch_bounds__(64 * WPB, (TileWm<R, LPS, WPB>::MIN_WAVES))
+// TPW = 2 (tracer batches only): a wave advects TWO tracers of its tile at once.  u, w, the
+// upwind selects, the u / w sums and the tracer-independent factors of the antidiffusive fluxes
+// (:571-573, :580-582) are fetched / formed once for both, the tracer state (register pipeline,
+// flux sums, store) is a Pair.
+template <typename R, int LPS, int WPB, bool STREAM, int TPW = 1>
+__global__ void __launch_bounds__(64 * WPB, (TileWm<R, LPS, WPB, TPW>::MIN_WAVES))
 mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
-  using T = TileWm<R, LPS, WPB>;
+  using T = TileWm<R, LPS, WPB, TPW>;
+  static_assert(TPW == 1 || (TPW == 2 && !STREAM), "two tracers per wave: batch form only");
+  using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
   constexpr int SLP = T::SLP, RB = (int)sizeof(R);
   __shared__ R lds[T::LDS_ELEMS];
 
@@ -97,14 +158,14 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   //      back to back on ONE XCD and all but the first find them in that XCD's L2.
   const unsigned ntr = (unsigned)a.ntracers;
   unsigned tile, tr;
-  if (ntr == 1) {
+  if (ntr == 1 && TPW == 1) {
     tile = blockIdx.x * WPB + wave;
     tr = 0;
   } else {
-    const unsigned nxcd = 8;
+    const unsigned nxcd = 8, ntw = (ntr + TPW - 1) / TPW;   // waves per tile
     const unsigned v = (blockIdx.x / nxcd) * WPB + wave;  // position in the XCD's wave sequence
-    tr = v % ntr;
-    tile = (v / ntr) * nxcd + blockIdx.x % nxcd;
+    tr = (v % ntw) * TPW;                                 // first tracer of the wave
+    tile = (v / ntw) * nxcd + blockIdx.x % nxcd;
   }
   if (tile >= (unsigned)a.ntiles) return;  // (no barrier anywhere below)
   // serpentine: every other run of a plan walks the tiles from the other end, so that it starts
@@ -119,6 +180,11 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   const R* const w = a.w + toff;
   const R* const kc = a.kc + (long long)tile * (3 * chunk);
   R* const flux = a.flux + (long long)tr * a.flux_tstride + (long long)tile * chunk;
+  // second tracer of the wave (TPW = 2); if it does not exist (odd ntracers) it is addressed through
+  // an EMPTY buffer range: its fetches deliver zeros, its stores are dropped
+  const bool has1 = TPW == 2 && tr + 1 < ntr;
+  R* const f1 = has1 ? f + a.f_tstride : f;
+  R* const flux1 = has1 ? flux + a.flux_tstride : flux;
 
   // ---- lane -> (instance s, level k) -----------------------------------------
   const int s_l = lane / LPS;
@@ -161,6 +227,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   const unsigned remBase = (unsigned)ncol * mainB;
   const long long tileB = (long long)ncol * chunkB;
   const __amdgpu_buffer_rsrc_t rsf = v2::make_rsrc(f, tileB);
+  const __amdgpu_buffer_rsrc_t rsf1 = v2::make_rsrc(f1, has1 ? tileB : 0);
   const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, tileB);
   const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, tileB);
   const unsigned posB = (unsigned)(pos * RB);
@@ -207,7 +274,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   };
   // store offset of column c = q - 1 of the step about to run; the march starts at q = -2, behind one
   // empty flush of the deferred-store slot, which advances the offset as well
-  unsigned scur = lvl_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) - 4u * cstride : OOB;
+  unsigned scur = lvl_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) - (TPW == 1 ? 4u : 3u) * cstride : OOB;
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   // pair P of all three arrays into its ring slot.  e*/o*: which columns of the pair exist for
@@ -226,17 +293,19 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
       // main-part fetch runs with the main lanes only, the remainder fetch with the others.
       if (lane_main) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)halves(vA, ef, of), (int)soA, 0, AUX_NT);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 16, (int)halves(vA, eu, ou), (int)soA, 0, AUX_NT);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 16, (int)halves(vA, ew, ow), (int)soA, 0, AUX_NT);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::UO), 16, (int)halves(vA, eu, ou), (int)soA, 0, AUX_NT);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + T::WO), 16, (int)halves(vA, ew, ow), (int)soA, 0, AUX_NT);
       } else {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)halves(vB, ef, of), (int)soB, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 16, (int)halves(vB, eu, ou), (int)soB, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 16, (int)halves(vB, ew, ow), (int)soB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::UO), 16, (int)halves(vB, eu, ou), (int)soB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + T::WO), 16, (int)halves(vB, ew, ow), (int)soB, 0, 0);
       }
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)halves(dcur, ef, of), 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::ARR), 16, (int)halves(dcur, eu, ou), 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + 2 * T::ARR), 16, (int)halves(dcur, ew, ow), 0, 0, 0);
+      const unsigned of_ = halves(dcur, ef, of);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)of_, 0, 0, 0);
+      if constexpr (TPW == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf1, (lds_ptr_t)(d + T::ARR), 16, (int)of_, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (lds_ptr_t)(d + T::UO), 16, (int)halves(dcur, eu, ou), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(d + T::WO), 16, (int)halves(dcur, ew, ow), 0, 0, 0);
       dcur = add_lo(dcur, strides);   // (pairs are issued in order, P = 0, 1, 2, ...)
     }
   };
@@ -252,12 +321,12 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   // (two instructions); else one instruction, every lane to its part.
   // AHEAD = 0: the step's regular store (column c = q - 1; advances the running offset);
   // AHEAD = 2: the early store of a halo column c = q + 1.
-  auto st_col = [&](const bool act, const int c, const R v, auto ahead_tag) __attribute__((always_inline)) {
+  auto st_col = [&](const bool act, const int c, const V v, auto ahead_tag) __attribute__((always_inline)) {
     constexpr int AHEAD = decltype(ahead_tag)::value;
 #ifdef MPD2_ABL_NOMEM  // timing ablation only (wrong results)
-    if (__builtin_bit_cast(double, v) != 1.2345e300) return;
+    if (__builtin_bit_cast(double, first(v)) != 1.2345e300) return;
 #endif
-    const v2::u32x2 b = __builtin_bit_cast(v2::u32x2, v);
+    const v2::u32x2 b = __builtin_bit_cast(v2::u32x2, first(v));
     if constexpr (STREAM) {
       __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)(act ? st_main : OOB), (int)((unsigned)c * mainB), AUX_NT);
       __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)(act ? st_rem : OOB), (int)((unsigned)c * remB), 0);
@@ -265,7 +334,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
       // (c is implied by the running offset)
       unsigned o = scur;
       if (AHEAD == 2) o = add_hi(add_hi(scur, strides), strides);
-      __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)(act ? o : OOB), 0, 0);
+      const unsigned oa = act ? o : OOB;
+      __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)oa, 0, 0);
+      if constexpr (TPW == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2::u32x2, second(v)), rsf1, (int)oa, 0, 0);
       if (AHEAD == 0) scur = add_hi(scur, strides);
     }
   };
@@ -282,8 +353,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int P = 0; P < T::NS; ++P) {
-    st_col(false, 0, R(0), std::integral_constant<int, 1>{});
-    st_col(false, 0, R(0), std::integral_constant<int, 1>{});
+    st_col(false, 0, V(R(0)), std::integral_constant<int, 1>{});
+    st_col(false, 0, V(R(0)), std::integral_constant<int, 1>{});
     dma_pair(P);
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -301,32 +372,64 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #else
   const R EPS_D = eps, LIM = R(1);
 #endif
-  Window<R> S;
+  const V ZV = V(R(0));
+  Window<V> S;   // the tracer state: register pipeline of the column march
+  Window<R> G;   // the rings of u, w and their sums (UR .. SU): common to the tracers of the wave
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    S.F0[j] = S.PMX[j] = S.PMN[j] = S.U1[j] = S.DW1[j] = R(0);
-    S.F1[j] = S.F1D[j] = S.F1U[j] = S.MX0[j] = S.MN0[j] = R(0);
-    S.UR[j] = S.UD[j] = S.PW[j] = S.SW[j] = S.WR[j] = S.SU[j] = S.U2P[j] = S.U2N[j] = R(0);
-    S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = R(0);
+    S.F0[j] = S.PMX[j] = S.PMN[j] = S.U1[j] = S.DW1[j] = ZV;
+    S.F1[j] = S.F1D[j] = S.F1U[j] = S.MX0[j] = S.MN0[j] = ZV;
+    G.UR[j] = G.UD[j] = G.PW[j] = G.SW[j] = G.WR[j] = G.SU[j] = R(0);
+    S.U2P[j] = S.U2N[j] = ZV;
+    S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = ZV;
   }
-  R S1 = R(0), S3 = R(0);
-  R v_def = R(0);   // the deferred store of a pair's odd column
+  V S1 = ZV, S3 = ZV;
+  V v_def = ZV;   // the deferred store of a pair's odd column
   bool act_def = false;
   int c_def = 0;
 
 
+  // a tracer-dependent input from the LDS ring (f of the wave's tracers: array blocks 0 .. TPW-1)
+  auto ldv = [&](const R* p) __attribute__((always_inline)) {
+    if constexpr (TPW == 1) return p[0];
+    else return V(p[0], p[T::ARR]);
+  };
+  // The LDS inputs of one column step.  One tracer per wave: the step reads them itself (`in` is
+  // not used: with 128 VGPRs they cannot be held ahead of time).  Two tracers per wave: the pair
+  // loop fetches them a whole step ahead of their use (software pipelining; with two waves per
+  // SIMD an exposed LDS round trip at the top of every step is not hidden by other waves).
+  struct LdsIn { V f0q, f0d, f0u; R uq, wq, ud, wu; };
+  auto lds_in = [&](auto sl_tag, auto h_tag) __attribute__((always_inline)) {
+    constexpr int LO = decltype(sl_tag)::value * T::SLOT + decltype(h_tag)::value * T::HALF;
+    LdsIn r;
+    r.f0q = ldv(p_own + LO);
+    r.uq = p_own[LO + T::UO];
+    r.wq = p_own[LO + T::WO];
+    if constexpr (LPS == 64) r.wq = lvl_ok ? r.wq : R(0);
+    r.f0d = ldv(p_dn + LO);
+    r.f0u = ldv(p_up + LO);
+    r.ud = p_dn[LO + T::UO];
+    r.wu = p_up[LO + T::WO];
+    return r;
+  };
   // One column step.  PH = c mod 3 selects the register ring slots, SL = (c/2) mod 3 the LDS
   // ring slot, H = c mod 2 the column of the pair (c = q+2); FULL = steady state (4 <= q <= nx).
-  auto step = [&](auto ph_tag, auto sl_tag, auto h_tag, auto full_tag, const int q) __attribute__((always_inline)) {
+  auto step = [&](auto ph_tag, auto sl_tag, auto h_tag, auto full_tag, const int q, const LdsIn& in) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph_tag)::value;
     constexpr int LO = decltype(sl_tag)::value * T::SLOT + decltype(h_tag)::value * T::HALF;  // LDS offset
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr int C0 = PH, C1 = (PH + 2) % 3, C2 = (PH + 1) % 3, C3 = PH;  // slots of q, q-1, q-2, q-3
 
-    const R f0q = p_own[LO];
-    const R uq = p_own[LO + T::ARR];
-    R wq = p_own[LO + 2 * T::ARR];  // ghost level: w = 0
-    if constexpr (LPS == 64) wq = lvl_ok ? wq : R(0);
+    V f0q;
+    R uq, wq;   // (ghost level: w = 0)
+    if constexpr (TPW == 1) {
+      f0q = ldv(p_own + LO);
+      uq = p_own[LO + T::UO];
+      wq = p_own[LO + T::WO];
+      if constexpr (LPS == 64) wq = lvl_ok ? wq : R(0);
+    } else {
+      f0q = in.f0q; uq = in.uq; wq = in.wq;
+    }
 
 #ifdef MPDWM_ABL_NOCOMPUTE  // timing ablation only: data movement without the arithmetic
     st_col(q - 3 >= -1 && q - 3 <= nx + 2, max(q - 1, 0), f0q + uq + wq, std::integral_constant<int, 0>{});
@@ -335,16 +438,21 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #define DN_C(x) shift_dn_clamped((x), own_dn)
 #define UP_C(x) shift_up_clamped((x), own_up)
 #define UP_G(x) shift_up(x)
-    const R f0d = p_dn[LO];
-    const R f0u = p_up[LO];
-    const R F0p = S.F0[C1];
+    V f0d, f0u;
+    if constexpr (TPW == 1) {
+      f0d = ldv(p_dn + LO);
+      f0u = ldv(p_up + LO);
+    } else {
+      f0d = in.f0d; f0u = in.f0u;
+    }
+    const V F0p = S.F0[C1];
 
     // ================= stage A =================================================
-    R U1q = R(0), DW1q = R(0), f1_1 = R(0), F1D_1 = R(0), F1U_1 = R(0), MX0_1 = R(0), MN0_1 = R(0);
+    V U1q = ZV, DW1q = ZV, f1_1 = ZV, F1D_1 = ZV, F1U_1 = ZV, MX0_1 = ZV, MN0_1 = ZV;
     if (FULL || (q >= -1 && q <= nx + 3)) {
       U1q = upwind(uq, F0p, f0q);  // :532
       if (FULL || q <= nx + 2) {
-        const R W1q = upwind(wq, f0d, f0q);  // :537
+        const V W1q = upwind(wq, f0d, f0q);  // :537
         DW1q = UP_G(W1q) - W1q;
         if (FULL || (q >= 1 && q <= nx)) S1 = S1 + W1q;  // :545
       }
@@ -372,35 +480,40 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     S.F0[C0] = f0q;
 
     // u / w sums for the antidiffusive cross terms (:573, :582), reference order
-    const R ud = p_dn[LO + T::ARR];
-    const R wu = p_up[LO + 2 * T::ARR];
+    R ud, wu;
+    if constexpr (TPW == 1) {
+      ud = p_dn[LO + T::UO];
+      wu = p_up[LO + T::WO];
+    } else {
+      ud = in.ud; wu = in.wu;
+    }
 #ifdef MPDATA_FAST_DIV
-    S.UD[C0] = uq + ud;                        // (the ring holds the pair sum here)
-    S.SU[C1] = S.UD[C1] + S.UD[C0];
-    S.PW[C0] = wq + wu;
-    S.SW[C0] = S.PW[C1] + S.PW[C0];
+    G.UD[C0] = uq + ud;                        // (the ring holds the pair sum here)
+    G.SU[C1] = G.UD[C1] + G.UD[C0];
+    G.PW[C0] = wq + wu;
+    G.SW[C0] = G.PW[C1] + G.PW[C0];
 #else
-    S.SU[C1] = S.UD[C1] + S.UR[C1] + uq + ud;  // u(i,kb)+u(i,k)+u(ic,k)+u(ic,kb), i = q-1
-    S.UD[C0] = ud;
-    S.SW[C0] = S.PW[C1] + wq + wu;             // w(ib,k)+w(ib,kc)+w(i,k)+w(i,kc), i = q
-    S.PW[C0] = wq + wu;
+    G.SU[C1] = G.UD[C1] + G.UR[C1] + uq + ud;  // u(i,kb)+u(i,k)+u(ic,k)+u(ic,kb), i = q-1
+    G.UD[C0] = ud;
+    G.SW[C0] = G.PW[C1] + wq + wu;             // w(ib,k)+w(ib,kc)+w(i,k)+w(i,kc), i = q
+    G.PW[C0] = wq + wu;
 #endif
-    S.UR[C0] = uq;
-    S.WR[C0] = wq;
+    G.UR[C0] = uq;
+    G.WR[C0] = wq;
 
     // ================= stage B/C ===============================================
-    R U2_1 = R(0), U2p_1 = R(0), U2n_1 = R(0), W2_2 = R(0), W2p = R(0), W2n = R(0), MXN_2 = R(0), MNN_2 = R(0);
+    V U2_1 = ZV, U2p_1 = ZV, U2n_1 = ZV, W2_2 = ZV, W2p = ZV, W2n = ZV, MXN_2 = ZV, MNN_2 = ZV;
     if (FULL || (q >= 1 && q <= nx + 3)) {
       {  // :571-573, column q-1
 #ifdef MPDATA_FAST_DIV
-        const R u1 = S.UR[C1];
+        const R u1 = G.UR[C1];
         const R t1 = rabs(u1) - (u1 * u1) * IRHO;
-        const R x4 = S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1;
-        U2_1 = t1 * (f1_1 - S.F1[C2]) - KU * ((u1 * S.SW[C1]) * x4);   // = 2 x (:571-573)
+        const V x4 = S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1;
+        U2_1 = t1 * (f1_1 - S.F1[C2]) - (KU * (u1 * G.SW[C1])) * x4;   // = 2 x (:571-573)
 #else
-        const R ad = andiff(S.F1[C2], f1_1, S.UR[C1], IRHO);
-        const R x = rldexp(IADZ * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1), dd_exp);
-        U2_1 = ad - across(x, S.UR[C1], S.SW[C1]) * IRHO;
+        const V ad = andiff_s(S.F1[C2], f1_1, G.UR[C1], IRHO);
+        const V x = rldexp(IADZ * (S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1), dd_exp);
+        U2_1 = ad - across_s(x, G.UR[C1], G.SW[C1]) * IRHO;
 #endif
         U2p_1 = pp(U2_1);
         U2n_1 = pn(U2_1);
@@ -408,30 +521,30 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
       if (FULL || q >= 2) {  // column q-2
         {  // :580-582, :586
 #ifdef MPDATA_FAST_DIV
-          const R w2 = S.WR[C2];
+          const R w2 = G.WR[C2];
           const R t1 = rabs(w2) - (w2 * w2) * IRHOW;
-          const R x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
-          W2_2 = t1 * (S.F1[C2] - S.F1D[C2]) - KW * ((w2 * S.SU[C2]) * x4);  // = 2 x (:580-582); k = 1: 0
+          const V x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
+          W2_2 = t1 * (S.F1[C2] - S.F1D[C2]) - (KW * (w2 * G.SU[C2])) * x4;  // = 2 x (:580-582); k = 1: 0
 #else
-          const R ad = andiff(S.F1D[C2], S.F1[C2], S.WR[C2], IRHOW);
-          const R x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
-          const R v = ad - across(x, S.WR[C2], S.SU[C2]) * IRHO;
-          W2_2 = k_is_1 ? R(0) : v;  // www(:,:,:,1) = 0 (:586)
+          const V ad = andiff_s(S.F1D[C2], S.F1[C2], G.WR[C2], IRHOW);
+          const V x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
+          const V v = ad - across_s(x, G.WR[C2], G.SU[C2]) * IRHO;
+          W2_2 = sel(k_is_1, ZV, v);  // www(:,:,:,1) = 0 (:586)
 #endif
         }
-        const R W2u = UP_C(W2_2);
+        const V W2u = UP_C(W2_2);
         // :596-597
-        const R mx1 = dmax(dmax(dmax(dmax(dmax(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MX0[C2]);
-        const R mn1 = dmin(dmin(dmin(dmin(dmin(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MN0[C2]);
+        const V mx1 = dmax(dmax(dmax(dmax(dmax(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MX0[C2]);
+        const V mn1 = dmin(dmin(dmin(dmin(dmin(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MN0[C2]);
         // :606-609
         W2p = pp(W2_2);
         W2n = pn(W2_2);
-        const R den_mx = U2n_1 + S.U2P[C2] + IADZ * (pn(W2u) + W2p) + EPS_D;
-        const R den_mn = U2p_1 + S.U2N[C2] + IADZ * (pp(W2u) + W2n) + EPS_D;
+        const V den_mx = U2n_1 + S.U2P[C2] + IADZ * (pn(W2u) + W2p) + EPS_D;
+        const V den_mn = U2p_1 + S.U2N[C2] + IADZ * (pp(W2u) + W2n) + EPS_D;
 #ifdef MPDATA_FAST_DIV
         {  // one reciprocal for both ratios (both denominators >= eps > 0, finite)
-          const R dd2 = den_mx * den_mn;
-          const R r = RHO * recip_nr(dd2);   // (rho once for both ratios)
+          const V dd2 = den_mx * den_mn;
+          const V r = RHO * recip_nr(dd2);   // (rho once for both ratios)
           MXN_2 = (mx1 - S.F1[C2]) * (den_mn * r);
           MNN_2 = (S.F1[C2] - mn1) * (den_mx * r);
         }
@@ -450,13 +563,13 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     S.MNN[C2] = MNN_2;
 
     // ================= stage D =================================================
-    R U3_2 = R(0), DW3_2 = R(0);
+    V U3_2 = ZV, DW3_2 = ZV;
     if (FULL || (q >= 3 && q <= nx + 3)) {
       U3_2 = S.U2P[C2] * dmin(MXN_2, S.MNN[C3]) - S.U2N[C2] * dmin(S.MXN[C3], MNN_2);  // :618
       if (FULL || q <= nx + 2) {
-        const R mxd = DN_C(MXN_2);
-        const R mnd = DN_C(MNN_2);
-        const R W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
+        const V mxd = DN_C(MXN_2);
+        const V mnd = DN_C(MNN_2);
+        const V W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
         S3 = S3 + W3;  // :624
         DW3_2 = UP_G(W3) - W3;
       }
@@ -464,13 +577,15 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     {
       const int n = q - 3;  // column finished in this step: stored straight from the register
       const bool act = n >= -1 && n <= nx + 2;
-      R v = S.F1[C3];  // halo columns keep the first-pass value (:557)
+      V v = S.F1[C3];  // halo columns keep the first-pass value (:557)
       if (FULL || (n >= 1 && n <= nx))
-        v = dmax(R(0), S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
+        v = dmax(ZV, S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
       // the odd column's store waits until the next pair has been waited for: the counted wait
       // must see every store issued after the pair's DMA complete, and a store issued right
       // before it would stall it for a store round trip (+1 % one tracer, +3.5 % tracer batches)
-      if constexpr (decltype(h_tag)::value == 1) {
+      // (two tracers per wave: the wait sits between the two steps of a pair, and it is the even
+      //  column's store that is held back past it)
+      if constexpr (decltype(h_tag)::value == (TPW == 1 ? 1 : 0)) {
         v_def = v; act_def = FULL || act; c_def = max(n + 2, 0);
       } else {
         st_col(FULL || act, max(n + 2, 0), v, std::integral_constant<int, 0>{});
@@ -507,37 +622,61 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 // before an older load has landed, and the count then drops below the mark with a DMA of the
 // pair still in flight; seen as sporadic wrong columns with default-policy stores.)
 #define MPDWM_FLUSH_DEFERRED st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
-#define MPDWM_PAIR(PHA, PHB, SL, TAG, q, DMA)           \
-  if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  \
-  MPDWM_FLUSH_DEFERRED                                  \
-  step(PHA{}, SL{}, I0{}, TAG{}, (q));                  \
-  asm volatile("" ::: "memory");                        \
-  step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1);              \
-  asm volatile("" ::: "memory");                        \
-  DMA((q) + 1);
+#define MPDWM_PAIR(PHA, PHB, SL, SLN, TAG, q, DMA)      \
+  if constexpr (TPW == 1) {                             \
+    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+    MPDWM_FLUSH_DEFERRED                                \
+    step(PHA{}, SL{}, I0{}, TAG{}, (q), in_e);          \
+    asm volatile("" ::: "memory");                      \
+    step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1, in_e);      \
+    asm volatile("" ::: "memory");                      \
+    DMA((q) + 1);                                       \
+  } else {                                              \
+    const LdsIn in_o = lds_in(SL{}, I1{});              \
+    step(PHA{}, SL{}, I0{}, TAG{}, (q), in_e);          \
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    \
+    MPDWM_FLUSH_DEFERRED                                \
+    in_e = lds_in(SLN{}, I0{});                         \
+    step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1, in_o);      \
+    asm volatile("" ::: "memory");                      \
+    DMA((q) + 1);                                       \
+  }
+  // Two tracers per wave: the LDS inputs of a step are read one step ahead (in_o at the top of the
+  // pair, the next pair's in_e in its middle, behind the wait for that pair: the only DMA group
+  // issued after it is the one of the pair after next -- 4 instructions).
+  LdsIn in_e;
+  if constexpr (TPW == 2) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // pair 0 (pairs 1, 2 were issued after it)
+    in_e = lds_in(I0{}, I0{});
+  }
   int q0 = -2;
   {  // fill: columns -2 .. 3 (nx >= 1: all of them exist)
-    MPDWM_PAIR(I0, I1, I0, Part, q0, dma_p)
-    MPDWM_PAIR(I2, I0, I1, Part, q0 + 2, dma_p)
-    MPDWM_PAIR(I1, I2, I2, Part, q0 + 4, dma_p)
+    MPDWM_PAIR(I0, I1, I0, I1, Part, q0, dma_p)
+    MPDWM_PAIR(I2, I0, I1, I2, Part, q0 + 2, dma_p)
+    MPDWM_PAIR(I1, I2, I2, I0, Part, q0 + 4, dma_p)
     q0 += 6;
   }
   for (; q0 + 5 <= nx; q0 += 6) {  // steady state
-    MPDWM_PAIR(I0, I1, I0, Full, q0, dma_f)
-    MPDWM_PAIR(I2, I0, I1, Full, q0 + 2, dma_f)
-    MPDWM_PAIR(I1, I2, I2, Full, q0 + 4, dma_f)
+    MPDWM_PAIR(I0, I1, I0, I1, Full, q0, dma_f)
+    MPDWM_PAIR(I2, I0, I1, I2, Full, q0 + 2, dma_f)
+    MPDWM_PAIR(I1, I2, I2, I0, Full, q0 + 4, dma_f)
   }
   for (; q0 <= q_last; q0 += 6) {  // drain
-    MPDWM_PAIR(I0, I1, I0, Part, q0, dma_p)
-    MPDWM_PAIR(I2, I0, I1, Part, q0 + 2, dma_p)
-    MPDWM_PAIR(I1, I2, I2, Part, q0 + 4, dma_p)
+    MPDWM_PAIR(I0, I1, I0, I1, Part, q0, dma_p)
+    MPDWM_PAIR(I2, I0, I1, I2, Part, q0 + 2, dma_p)
+    MPDWM_PAIR(I1, I2, I2, I0, Part, q0 + 4, dma_p)
   }
 #undef MPDWM_PAIR
 #undef MPDWM_FLUSH_DEFERRED
 
-  st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
-  if (lvl_ok) flux[pos] = S1 + S3;  // :541-547, :624
+  if constexpr (TPW == 1) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
+  {  // flux (:541-547, :624)
+    const V fl = S1 + S3;
+    if (lvl_ok) flux[pos] = first(fl);
+    if constexpr (TPW == 2)
+      if (lvl_ok && has1) flux1[pos] = second(fl);
+  }
 }
 
 }  // namespace wm

@@ -99,6 +99,21 @@ namespace {
     if (rc_) return rc_;       \
   } while (0)
 
+// MPDATA_MULTI_TRACE=1: one stderr line per step of scatter / gather (diagnosis of stalls)
+bool trace_on() {
+  static const bool on = getenv("MPDATA_MULTI_TRACE") != nullptr;
+  return on;
+}
+#define M_TRACE(...)                                   \
+  do {                                                 \
+    if (trace_on()) {                                  \
+      fprintf(stderr, "[mpdata_multi %.3f] ", now_s()); \
+      fprintf(stderr, __VA_ARGS__);                    \
+      fputc('\n', stderr);                             \
+      fflush(stderr);                                  \
+    }                                                  \
+  } while (0)
+
 unsigned grid_for(long long total) {
   long long g = (total + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -111,6 +126,21 @@ int sync_all(mpdata_multi* m) {
   }
   return 0;
 }
+
+// Page-locks a caller's host array for the lifetime of the object (no-op if the caller has
+// registered it already, or if the runtime refuses: the copies then go through its staging path).
+struct HostPin {
+  void* p = nullptr;
+  HostPin(const void* host, size_t bytes) {
+    if (hipHostRegister(const_cast<void*>(host), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(host);
+    else (void)hipGetLastError();
+  }
+  ~HostPin() {
+    if (p) (void)hipHostUnregister(p);
+  }
+  HostPin(const HostPin&) = delete;
+  HostPin& operator=(const HostPin&) = delete;
+};
 
 // which: 0 f, 1 u, 2 w, 3 rho, 4 rhow, 5 adz, 6 flux
 size_t rows_of(const mpdata_multi* m, int which) {
@@ -134,14 +164,24 @@ int import_block(mpdata_multi* m, int g, int which, int tracer) {
 int scatter_array(mpdata_multi* m, int which, const void* host, int tracer) {
   const size_t rows = rows_of(m, which), eb = (size_t)m->eb;
   const int G = m->ngpus;
+  M_TRACE("scatter array %d tracer %d transport %d", which, tracer, (int)m->xfer);
   if (m->xfer == XFER_DIRECT) {
-    for (int g = 0; g < G; ++g) {
-      M_HIP(hipSetDevice(m->dev[g]));
-      M_HIP(hipMemcpy2DAsync(m->rb[g], (size_t)m->nloc[g] * eb, (const char*)host + (size_t)m->sl0[g] * eb,
-                             (size_t)m->ncrms * eb, (size_t)m->nloc[g] * eb, rows, hipMemcpyHostToDevice, m->stream[g]));
-      M_TRY(import_block(m, g, which, tracer));
+    // every GPU pulls its own slab: the array is page-locked for the duration, so that the strided
+    // copies are plain DMA from the caller's memory (no staging inside the runtime)
+    HostPin pin(host, rows * (size_t)m->ncrms * eb);
+    int rc = 0;
+    for (int g = 0; g < G && !rc; ++g) {
+      hipError_t e = hipSetDevice(m->dev[g]);
+      if (e == hipSuccess)
+        e = hipMemcpy2DAsync(m->rb[g], (size_t)m->nloc[g] * eb, (const char*)host + (size_t)m->sl0[g] * eb,
+                             (size_t)m->ncrms * eb, (size_t)m->nloc[g] * eb, rows, hipMemcpyHostToDevice, m->stream[g]);
+      if (e != hipSuccess) rc = mpdata_internal_set_err((int)e, "direct scatter to device %d: %s", m->dev[g], hipGetErrorString(e));
+      if (!rc) rc = import_block(m, g, which, tracer);
     }
-    return sync_all(m);
+    M_TRACE("direct scatter: copies + imports queued, rc=%d", rc);
+    const int rs = sync_all(m);   // (before the array is unpinned, also on the error path)
+    M_TRACE("direct scatter: synchronised");
+    return rc ? rc : rs;
   }
   // root: full-width copy in, one pack per GPU (the root's own block straight into its buffer)
   M_HIP(hipSetDevice(m->dev[0]));
@@ -153,6 +193,7 @@ int scatter_array(mpdata_multi* m, int which, const void* host, int tracer) {
                        (long long)m->sl0[g], (long long)m->nloc[g], m->eb, 0);
   }
   M_HIP(hipGetLastError());
+  M_TRACE("scatter: staged + packed");
   if (m->xfer == XFER_RCCL) {
     const ncclDataType_t dt = m->eb == 8 ? ncclDouble : ncclFloat;
     M_NCCL(ncclGroupStart());
@@ -169,28 +210,38 @@ int scatter_array(mpdata_multi* m, int which, const void* host, int tracer) {
       M_HIP(hipMemcpyPeerAsync(m->rb[g], m->dev[g], m->pk[g], m->dev[0], rows * (size_t)m->nloc[g] * eb, m->stream[g]));
     }
   }
+  M_TRACE("scatter: transfers queued");
   for (int g = 0; g < G; ++g) {
     M_HIP(hipSetDevice(m->dev[g]));
     M_TRY(import_block(m, g, which, tracer));
   }
-  return sync_all(m);
+  M_TRACE("scatter: imports queued");
+  const int rs = sync_all(m);
+  M_TRACE("scatter: synchronised");
+  return rs;
 }
 
 // f (which = 0) or flux (6) of one tracer from every GPU's plan to the host array.
 int gather_array(mpdata_multi* m, int which, void* host, int tracer) {
   const size_t rows = rows_of(m, which), eb = (size_t)m->eb;
   const int G = m->ngpus;
+  M_TRACE("gather array %d tracer %d transport %d", which, tracer, (int)m->xfer);
   for (int g = 0; g < G; ++g) {
     M_HIP(hipSetDevice(m->dev[g]));
     M_TRY(mpdata_plan_export_device(m->sub[g], which == 0 ? m->rb[g] : nullptr, which == 6 ? m->rb[g] : nullptr, tracer, 1));
   }
   if (m->xfer == XFER_DIRECT) {
-    for (int g = 0; g < G; ++g) {
-      M_HIP(hipSetDevice(m->dev[g]));
-      M_HIP(hipMemcpy2DAsync((char*)host + (size_t)m->sl0[g] * eb, (size_t)m->ncrms * eb, m->rb[g], (size_t)m->nloc[g] * eb,
-                             (size_t)m->nloc[g] * eb, rows, hipMemcpyDeviceToHost, m->stream[g]));
+    HostPin pin(host, rows * (size_t)m->ncrms * eb);
+    int rc = 0;
+    for (int g = 0; g < G && !rc; ++g) {
+      hipError_t e = hipSetDevice(m->dev[g]);
+      if (e == hipSuccess)
+        e = hipMemcpy2DAsync((char*)host + (size_t)m->sl0[g] * eb, (size_t)m->ncrms * eb, m->rb[g], (size_t)m->nloc[g] * eb,
+                             (size_t)m->nloc[g] * eb, rows, hipMemcpyDeviceToHost, m->stream[g]);
+      if (e != hipSuccess) rc = mpdata_internal_set_err((int)e, "direct gather from device %d: %s", m->dev[g], hipGetErrorString(e));
     }
-    return sync_all(m);
+    const int rs = sync_all(m);
+    return rc ? rc : rs;
   }
   if (m->xfer == XFER_RCCL) {
     const ncclDataType_t dt = m->eb == 8 ? ncclDouble : ncclFloat;
@@ -209,6 +260,7 @@ int gather_array(mpdata_multi* m, int which, void* host, int tracer) {
       M_HIP(hipStreamSynchronize(m->stream[g]));
     }
   }
+  M_TRACE("gather: transfers done / queued");
   M_HIP(hipSetDevice(m->dev[0]));
   for (int g = 0; g < G; ++g) {
     const void* src = g == 0 ? m->rb[0] : m->pk[g];
@@ -218,7 +270,10 @@ int gather_array(mpdata_multi* m, int which, void* host, int tracer) {
   }
   M_HIP(hipGetLastError());
   M_HIP(hipMemcpyAsync(host, m->stage_full, rows * (size_t)m->ncrms * eb, hipMemcpyDeviceToHost, m->stream[0]));
-  return sync_all(m);
+  M_TRACE("gather: unpack + copy out queued");
+  const int rs = sync_all(m);
+  M_TRACE("gather: synchronised");
+  return rs;
 }
 
 }  // namespace
@@ -402,6 +457,7 @@ mpdata_plan* mpdata_multi_sub(const mpdata_multi* m, int g) { return (g >= 0 && 
 
 int mpdata_multi_destroy(mpdata_multi* m) {
   if (!m) return 0;
+  M_TRACE("destroy (%d GPUs)", m->ngpus);
   int prev = 0;
   (void)hipGetDevice(&prev);
   if (m->comm_ok)

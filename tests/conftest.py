@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # MPDATA_TEST_WATCHDOG=<seconds>: dump every thread's Python stack whenever the run has made no
+    # progress for that long (diagnosis of a stall; the run goes on)
+    wd = os.environ.get("MPDATA_TEST_WATCHDOG")
+    if wd:
+        import faulthandler
+        faulthandler.dump_traceback_later(float(wd), repeat=True, file=sys.stderr)
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -112,6 +112,34 @@ def test_batch_form_of_the_kernel_on_single_tracers(M, oracle, monkeypatch, shap
     assert_parity(M, oracle, var, 3, f, flux, f_ref, flux_ref)
 
 
+@pytest.mark.parametrize("shape", [(64, 32, 28), (37, 32, 17), (21, 33, 33), (10, 6, 64), (130, 31, 12), (7, 2, 4)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("ntr", [2, 3])
+@pytest.mark.parametrize("mode", ["exact", "fast", "exact-one-tracer-per-wave", "exact-odd-tracer-in-the-batch"])
+def test_tracer_batches_two_tracers_per_wave(M, oracle, monkeypatch, shape, ntr, mode):
+    """Tracer batches run TWO tracers per wave (u, w and the tracer-independent factors formed once
+    for both); the last tracer of an odd count goes through the one-tracer kernel, or -- with
+    MPDATA_WM_NOSPLIT -- stays in the batch launch paired with an empty buffer range.  Every tracer
+    must equal a single-tracer call of the oracle, on all lane mappings (nz <= 8 / 16 / 32 / 64) and
+    ragged tile counts.  MPDATA_WM_TPW1 keeps the one-tracer-per-wave batch kernel covered."""
+    if mode.endswith("per-wave"):
+        monkeypatch.setenv("MPDATA_WM_TPW1", "1")
+    if mode.endswith("in-the-batch"):
+        monkeypatch.setenv("MPDATA_WM_NOSPLIT", "1")
+    var = M.VARIANT_FAST if mode == "fast" else M.VARIANT_EXACT
+    M.set_variant(var)
+    ncrms, nx, nz = shape
+    base = oracle.make_inputs(ncrms, nx, nz, seed=21, dist=3)
+    fs = [oracle.make_inputs(ncrms, nx, nz, seed=210 + t, dist=3)["f"] for t in range(ntr)]
+    inp = dict(base)
+    inp["f"] = np.asfortranarray(np.stack(fs, axis=-1))
+    inp["flux"] = np.asfortranarray(np.stack([base["flux"]] * ntr, axis=-1))
+    f, flux = run_plan_host(M, inp, ntr=ntr)
+    for t in range(ntr):
+        f_ref, flux_ref = oracle.advect(dict(base, f=fs[t].copy()), nthreads=4)
+        assert_parity(M, oracle, var, 3, f[..., t], flux[..., t], f_ref, flux_ref)
+
+
 @pytest.mark.parametrize("variant", ["exact", "fast"])
 def test_wavemajor_tracer_batch_and_subranges(M, oracle, variant):
     """T tracers sharing u, w, rho, rhow, adz == T single-tracer calls of the oracle; a sub-range

@@ -23,7 +23,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACT
 # 25 tracers: kernel trace, HBM traffic, L2 hit rate, SQ
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t25_kt -o run -- python3 $ROOT/bench.py --steps 20 --warmup 2 $X > $OUT/t25_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/t25_fetch -o run -- $T > $OUT/t25_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/t25_write -o run -- $T > $OUT/t25_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/t25_write -o run -- $T > $OUT/t25_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/t25_tcc -o run -- $T > $OUT/t25_tcc.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/t25_sq -o run -- $T > $OUT/t25_sq.log 2>&1
 # reference-layout device call (x-march kernel): HBM traffic

@@ -16,6 +16,7 @@ ap.add_argument("--no-t25", action="store_true")
 ap.add_argument("--no-ref", action="store_true")
 ap.add_argument("--no-t1", action="store_true")
 ap.add_argument("--t25-steps", type=int, default=6)
+ap.add_argument("--tracers", type=int, default=25, help="tracers of the batch run")
 a = ap.parse_args()
 M.set_variant(M.VARIANT_FAST if a.variant == "fast" else M.VARIANT_EXACT)
 dev = torch.device("cuda", 0)
@@ -66,7 +67,7 @@ if not a.no_ref:
     print(f"device call x-march T=1 : {ms:.4f} ms  {cells / ms / 1e6:.1f} Gcu/s  frac {ab / ms / 1e6 / 8000:.3f}")
     del fs
 if not a.no_t25:
-    T = 25
+    T = a.tracers
     p = M.Plan(ncrms, nx, nz, T)
     p.set_stream()
     p.import_device(None, d["u"], d["w"], d["rho"], d["rhow"], d["adz"], None)
@@ -76,5 +77,5 @@ if not a.no_t25:
     torch.cuda.synchronize()
     ms = timed(lambda i: p.run(), a.t25_steps, 3 if a.t25_steps > 1 else 0)
     ab = M.algorithmic_bytes(ncrms, nx, nz, T)
-    print(f"plan wave-major  T=25: {ms:.4f} ms  {cells * T / ms / 1e6:.1f} Gcu/s  {ab / ms / 1e6:.0f} GB/s  frac {ab / ms / 1e6 / 8000:.3f}")
+    print(f"plan wave-major  T={T}: {ms:.4f} ms  {cells * T / ms / 1e6:.1f} Gcu/s  {ab / ms / 1e6:.0f} GB/s  frac {ab / ms / 1e6 / 8000:.3f}")
     p.close()
