@@ -209,14 +209,20 @@ __device__ __forceinline__ R shift_up(R x) { return dpp_mov<MPD_DPP_WAVE_SHL1>(x
 // ... with the clamps kb = max(1,k-1) / kc = min(nzm,k+1): `own` is the wave mask of the
 // lanes that keep their own value.  Select and move are ONE instruction per 32-bit register
 // (v_cndmask_b32 with a DPP source operand; hipcc emits v_mov_b32_dpp + v_cndmask_b32 for
-// the same thing written in C).  s_nop 1: a DPP operand written by the preceding VALU
-// instruction needs two wait states, which the compiler cannot see inside an asm block.
+// the same thing written in C).  A DPP operand written by the preceding VALU instruction needs
+// two wait states, which the compiler cannot see inside an asm block: the mask move and an
+// s_nop 0 are those two.
 // Executed by ALL lanes (under a divergent EXEC mask a switched-off source lane counts as
 // missing).
+#ifdef MPD_DPP_NOP1   // (experiment: the longer wait)
+#define MPD_DPP_NOP "s_nop 1"
+#else
+#define MPD_DPP_NOP "s_nop 0"
+#endif
 #define MPD_CNDMASK_DPP64(CTRL)                                                                \
   int lo, hi;                                                                                  \
   const int xl = __double2loint(x), xh = __double2hiint(x);                                    \
-  asm("s_mov_b64 vcc, %4\n\ts_nop 1\n\t"                                                      \
+  asm("s_mov_b64 vcc, %4\n\t" MPD_DPP_NOP "\n\t"                                                      \
       "v_cndmask_b32_dpp %0, %2, %2, vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
       "v_cndmask_b32_dpp %1, %3, %3, vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0"      \
       : "=&v"(lo), "=&v"(hi)                                                                   \
@@ -226,7 +232,7 @@ __device__ __forceinline__ R shift_up(R x) { return dpp_mov<MPD_DPP_WAVE_SHL1>(x
 #define MPD_CNDMASK_DPP32(CTRL)                                                                \
   int r;                                                                                       \
   const int xi = __builtin_bit_cast(int, x);                                                   \
-  asm("s_mov_b64 vcc, %2\n\ts_nop 1\n\t"                                                      \
+  asm("s_mov_b64 vcc, %2\n\t" MPD_DPP_NOP "\n\t"                                                      \
       "v_cndmask_b32_dpp %0, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0"      \
       : "=&v"(r)                                                                               \
       : "v"(xi), "s"(own)                                                                      \

@@ -84,12 +84,29 @@ template <typename R> __device__ __forceinline__ Pair<R> rldexp(Pair<R> x, int e
 template <typename R> __device__ __forceinline__ Pair<R> recip_nr(Pair<R> x) { return {recip_nr(x.a), recip_nr(x.b)}; }
 template <typename R> __device__ __forceinline__ Pair<R> shift_dn(Pair<R> x) { return {shift_dn(x.a), shift_dn(x.b)}; }
 template <typename R> __device__ __forceinline__ Pair<R> shift_up(Pair<R> x) { return {shift_up(x.a), shift_up(x.b)}; }
+// clamped shifts of a pair: ONE mask move and ONE hazard wait (see v2::shift_dn_clamped)
+// for the four 32-bit select-moves
+#define MPDWM_CNDMASK_DPP_PAIR(CTRL)                                                             \
+  const v2::u32x2 xa = __builtin_bit_cast(v2::u32x2, x.a), xb = __builtin_bit_cast(v2::u32x2, x.b); \
+  v2::u32x2 ra, rb;                                                                              \
+  asm("s_mov_b64 vcc, %8\n\t" MPD_DPP_NOP "\n\t"                                                        \
+      "v_cndmask_b32_dpp %0, %4, %4, vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"   \
+      "v_cndmask_b32_dpp %1, %5, %5, vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"   \
+      "v_cndmask_b32_dpp %2, %6, %6, vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"   \
+      "v_cndmask_b32_dpp %3, %7, %7, vcc " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0"        \
+      : "=&v"(ra.x), "=&v"(ra.y), "=&v"(rb.x), "=&v"(rb.y)                                       \
+      : "v"(xa.x), "v"(xa.y), "v"(xb.x), "v"(xb.y), "s"(own)                                     \
+      : "vcc");                                                                                  \
+  return {__builtin_bit_cast(R, ra), __builtin_bit_cast(R, rb)};
 template <typename R> __device__ __forceinline__ Pair<R> shift_dn_clamped(Pair<R> x, unsigned long long own) {
-  return {shift_dn_clamped(x.a, own), shift_dn_clamped(x.b, own)};
+  static_assert(sizeof(R) == 8, "8-byte elements");
+  MPDWM_CNDMASK_DPP_PAIR("wave_shr:1")
 }
 template <typename R> __device__ __forceinline__ Pair<R> shift_up_clamped(Pair<R> x, unsigned long long own) {
-  return {shift_up_clamped(x.a, own), shift_up_clamped(x.b, own)};
+  static_assert(sizeof(R) == 8, "8-byte elements");
+  MPDWM_CNDMASK_DPP_PAIR("wave_shl:1")
 }
+#undef MPDWM_CNDMASK_DPP_PAIR
 // upwind flux with a shared velocity (:532, :537): a * (a >= 0 ? x : y) per tracer
 template <typename R> __device__ __forceinline__ Pair<R> upwind(R a, Pair<R> x, Pair<R> y) {
   return {a * v2::sel_ge0(a, x.a, y.a), a * v2::sel_ge0(a, x.b, y.b)};
