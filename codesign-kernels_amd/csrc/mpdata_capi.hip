@@ -830,8 +830,10 @@ int mpdata_plan_destroy(mpdata_plan* p) {
 // so the device -> host leg is driven by a second host thread: both PCIe directions are then
 // busy at once without page-locking anything.  Page-locking the caller's arrays for one call
 // does not pay (hipHostRegister: 20 ms per 538 MB, tools/h2d_rate.hip, against 10 ms to copy
-// them); MPDATA_HOST_PIN=1 does it anyway, and arrays the CALLER has registered are simply
-// used as they are (the copies are then true asynchronous DMA).
+// them) and is not done: the library never registers or unregisters caller memory (with this
+// runtime a later copy from a recycled address of a once-registered range ended in a GPU memory
+// access fault).  Arrays the CALLER has registered are simply used as they are (the copies are
+// then true asynchronous DMA).
 // MPDATA_HOST_CHUNK=<instances per chunk> (default ncrms/8, at least 1024, a multiple of 64).
 namespace {
 struct ChunkBufs {
@@ -853,22 +855,6 @@ int64_t host_chunk(int64_t ncrms) {
   c = (c + 63) / 64 * 64;
   return c < ncrms ? c : ncrms;
 }
-bool host_pin() {
-  const char* v = getenv("MPDATA_HOST_PIN");
-  return v && atoi(v) == 1;
-}
-struct Pinned {
-  void* p = nullptr;
-  bool mine = false;
-};
-Pinned pin_region(const void* p, size_t bytes) {
-  Pinned r;
-  r.p = const_cast<void*>(p);
-  const hipError_t e = hipHostRegister(r.p, bytes, hipHostRegisterDefault);
-  r.mine = e == hipSuccess;
-  if (e != hipSuccess) (void)hipGetLastError();  // already registered, or not registrable: use as is
-  return r;
-}
 struct OutJob {
   int set;
   int64_t c0, cw;
@@ -888,12 +874,6 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
   const size_t rows_f = (size_t)(nx + 6) * nzm * ntracers, rows_u = (size_t)(nx + 5) * nzm,
                rows_w = (size_t)(nx + 4) * nz, rows_k = nzm, rows_kz = (size_t)nz, rows_x = (size_t)nz * ntracers;
   const size_t hp = (size_t)ncrms * 8;  // host pitch: one row of all instances
-  Pinned pins[7];
-  if (host_pin()) {
-    const void* hptr[7] = {f, u, w, rho, rhow, adz, flux};
-    const size_t hrows[7] = {rows_f, rows_u, rows_w, rows_k, rows_kz, rows_k, rows_x};
-    for (int i = 0; i < 7; ++i) pins[i] = pin_region(hptr[i], hrows[i] * hp);
-  }
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   ChunkBufs set[3];
@@ -989,8 +969,6 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
       (void)hipStreamDestroy(st);
     }
   for (int i = 0; i < 3; ++i) free_chunk(set[i]);
-  for (int i = 0; i < 7; ++i)
-    if (pins[i].mine) (void)hipHostUnregister(pins[i].p);
   if (rc) return rc;
   if (e != hipSuccess) return hip_err(e, "mpdata_advect_scalar2d (streamed host call)");
   return 0;

@@ -127,21 +127,6 @@ int sync_all(mpdata_multi* m) {
   return 0;
 }
 
-// Page-locks a caller's host array for the lifetime of the object (no-op if the caller has
-// registered it already, or if the runtime refuses: the copies then go through its staging path).
-struct HostPin {
-  void* p = nullptr;
-  HostPin(const void* host, size_t bytes) {
-    if (hipHostRegister(const_cast<void*>(host), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(host);
-    else (void)hipGetLastError();
-  }
-  ~HostPin() {
-    if (p) (void)hipHostUnregister(p);
-  }
-  HostPin(const HostPin&) = delete;
-  HostPin& operator=(const HostPin&) = delete;
-};
-
 // which: 0 f, 1 u, 2 w, 3 rho, 4 rhow, 5 adz, 6 flux
 size_t rows_of(const mpdata_multi* m, int which) {
   const size_t nzm = (size_t)m->nz - 1;
@@ -166,9 +151,8 @@ int scatter_array(mpdata_multi* m, int which, const void* host, int tracer) {
   const int G = m->ngpus;
   M_TRACE("scatter array %d tracer %d transport %d", which, tracer, (int)m->xfer);
   if (m->xfer == XFER_DIRECT) {
-    // every GPU pulls its own slab: the array is page-locked for the duration, so that the strided
-    // copies are plain DMA from the caller's memory (no staging inside the runtime)
-    HostPin pin(host, rows * (size_t)m->ncrms * eb);
+    // every GPU pulls its own slab (the library does not page-lock caller memory, see
+    // mpdata_capi.hip: the runtime stages the strided copies)
     int rc = 0;
     for (int g = 0; g < G && !rc; ++g) {
       hipError_t e = hipSetDevice(m->dev[g]);
@@ -179,7 +163,7 @@ int scatter_array(mpdata_multi* m, int which, const void* host, int tracer) {
       if (!rc) rc = import_block(m, g, which, tracer);
     }
     M_TRACE("direct scatter: copies + imports queued, rc=%d", rc);
-    const int rs = sync_all(m);   // (before the array is unpinned, also on the error path)
+    const int rs = sync_all(m);   // (also on the error path: nothing may be left in flight)
     M_TRACE("direct scatter: synchronised");
     return rc ? rc : rs;
   }
@@ -231,7 +215,6 @@ int gather_array(mpdata_multi* m, int which, void* host, int tracer) {
     M_TRY(mpdata_plan_export_device(m->sub[g], which == 0 ? m->rb[g] : nullptr, which == 6 ? m->rb[g] : nullptr, tracer, 1));
   }
   if (m->xfer == XFER_DIRECT) {
-    HostPin pin(host, rows * (size_t)m->ncrms * eb);
     int rc = 0;
     for (int g = 0; g < G && !rc; ++g) {
       hipError_t e = hipSetDevice(m->dev[g]);
