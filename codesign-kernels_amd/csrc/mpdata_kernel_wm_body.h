@@ -518,6 +518,18 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     G.UR[C0] = uq;
     G.WR[C0] = wq;
 
+#ifdef MPDWM_ABL_FIRSTPASS  // timing ablation only (wrong results): stop after the first (upwind) pass
+    {
+      const bool act = q - 3 >= -1 && q - 3 <= nx + 2;
+      const V vs = f1_1 + S.F1[C2] + S.MX0[C2] + S.MN0[C2] + S1 + (G.SU[C1] + G.SW[C0]);
+      if constexpr (decltype(h_tag)::value == (TPW == 1 ? 1 : 0)) {
+        v_def = vs; act_def = FULL || act; c_def = max(q - 1, 0);
+      } else {
+        st_col(FULL || act, max(q - 1, 0), vs, std::integral_constant<int, 0>{});
+      }
+      return;
+    }
+#endif
     // ================= stage B/C ===============================================
     V U2_1 = ZV, U2p_1 = ZV, U2n_1 = ZV, W2_2 = ZV, W2p = ZV, W2n = ZV, MXN_2 = ZV, MNN_2 = ZV;
     if (FULL || (q >= 1 && q <= nx + 3)) {
