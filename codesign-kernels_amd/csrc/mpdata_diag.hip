@@ -1,7 +1,8 @@
 // mpdata_diag.hip -- diagnostic: what this GPU sustains for the routine's own traffic mix
 // (three arrays read, one written, in place) with the friendliest possible access pattern: every
 // workgroup moves one contiguous, aligned 16-KiB piece of each array with 16-byte loads / stores,
-// all loads issued before the first store.  bench.py prints it beside the 8 TB/s specification
+// all loads issued before the first store.  The arrays hold pseudo-random values (on all-zero
+// data the chip clocks higher and the figure flatters: DESIGN.md section 4.6).  bench.py prints it beside the 8 TB/s specification
 // ("also record a measured ... ceiling on the box").  Not on the hot path.
 #include <hip/hip_runtime.h>
 
@@ -23,8 +24,19 @@ __global__ void __launch_bounds__(256) stream_3r1w(const d2* a, const d2* b, con
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const size_t i = base + j * 256;
-    if (NT) __builtin_nontemporal_store(x[j] + y[j] + z[j], o + i);
-    else o[i] = x[j] + y[j] + z[j];
+    const d2 r = (x[j] + y[j] + z[j]) * 0.3125;   // (in place over many launches: stays O(1))
+    if (NT) __builtin_nontemporal_store(r, o + i);
+    else o[i] = r;
+  }
+}
+// pseudo-random doubles in [-1, 1): splitmix64 of the element index
+__global__ void __launch_bounds__(256) fill_random(double* a, size_t n, unsigned long long seed) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    a[i] = (double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
   }
 }
 }  // namespace
@@ -39,7 +51,10 @@ extern "C" int mpdata_diag_stream_3r1w(int64_t bytes_per_array, int nontemporal,
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e == hipSuccess) e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
-  for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipMemset(buf[i], 0, bytes);
+  for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+    hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (double*)buf[i], bytes / 8, 1234567ull + (unsigned long long)i);
+    e = hipGetLastError();
+  }
   float ms = 0.f;
   if (e == hipSuccess) {
     auto launch = [&]() {   // in place: the output is the first input, as f is in the routine

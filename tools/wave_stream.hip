@@ -16,10 +16,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
 }
 #define OOB 0xFFFFFFF8u
 
+__global__ void __launch_bounds__(256) fill_random(double* a, size_t n, unsigned long long seed) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    a[i] = (double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+  }
+}
+
 // MODE 0: 16-B DMA, one instruction per array and column PAIR (864 B), ring of NS pairs
 // MODE 1: 4-B DMA, two instructions per array and column (432 B), ring of NS columns
 // MODE 2: register loads (buffer_load_dwordx2 per lane), software pipeline depth NS columns
-template <int MODE, int NS, int WPB, int LA = 0, int SA = 0>
+template <int MODE, int NS, int WPB, int LA = 0, int SA = 0, int AH = NS - 1, int WN = 10>
 __global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, const char* w, char* fo,
                                                   int ntiles, int ncol, int chunkB, long long tileB, int tmap) {
   const int lane = threadIdx.x & 63;
@@ -218,12 +228,19 @@ __global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, 
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(d + 256), 16, (int)vB, (int)soB, 0, 0);
       }
     };
-    for (int p = 0; p < NS - 1; ++p) {
+    // AH pairs in flight while one is worked on (AH = NS: the slot is refilled right after it was
+    // read); WN = operations allowed outstanding at the wait: 10 counts the 4 stores of a pair as
+    // well (AH = 2), 6 * (AH - 1) counts only the newer fetches (the safe wait of the kernel)
+    for (int p = 0; p < AH; ++p) {
       for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0, 0}, ro, (int)OOB, 0, 0);
       dma(p);
     }
     for (int p = 0; p < npair; ++p) {
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      if constexpr (WN == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if constexpr (WN == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (WN == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if constexpr (WN == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
       const double* s = my + (p % NS) * 3 * 128;
       const int kl = lane * 8 < chunkB ? lane : 0;
       const double a0 = s[kl] + s[128 + kl] + s[256 + kl];
@@ -233,7 +250,7 @@ __global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, 
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)sB, (int)(p * 2 * remB), 0);
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)sA, (int)((p * 2 + 1) * mainB), SA);
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)sB, (int)((p * 2 + 1) * remB), 0);
-      dma(p + NS - 1);
+      dma(p + AH);
     }
   } else {
     // register-staged: NS columns of (f,u,w) in flight per lane
@@ -259,7 +276,7 @@ __global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, 
   }
 }
 
-template <int MODE, int NS, int WPB, int LA = 0, int SA = 0>
+template <int MODE, int NS, int WPB, int LA = 0, int SA = 0, int AH = NS - 1, int WN = 10>
 void run(const char* f, const char* u, const char* w, char* fo, int ntiles, int ncol, int chunkB, long long tileB, const char* tag, int tmap = 0, int ldsper = 10240) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int blocks = (ntiles + WPB - 1) / WPB;
@@ -267,14 +284,14 @@ void run(const char* f, const char* u, const char* w, char* fo, int ntiles, int 
   const int stat = (MODE == 0 || MODE >= 3) ? NS * 3 * 1024 : MODE == 1 ? NS * 3 * 512 : 0;
   const int dyn = stat < ldsper ? WPB * (ldsper - stat) : 0;
   for (int r = 0; r < 60; ++r)
-    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB, tmap);
+    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA, AH, WN>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB, tmap);
   (void)hipEventRecord(e0);
   for (int r = 0; r < 60; ++r)
-    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB, tmap);
+    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA, AH, WN>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB, tmap);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 60;
   const double bytes = (double)ntiles * ncol * chunkB * 4;
-  printf("%-10s tmap %d lds/wave %d LA %d SA %d mode %d ring %d waves/wg %d tileB %lld: %.3f ms  %.2f TB/s (err %d)\n", tag, tmap, ldsper, LA, SA, MODE, NS, WPB, tileB, ms,
+  printf("%-10s tmap %d lds/wave %d LA %d SA %d mode %d ring %d ahead %d wait %d waves/wg %d tileB %lld: %.3f ms  %.2f TB/s (err %d)\n", tag, tmap, ldsper, LA, SA, MODE, NS, AH, WN, WPB, tileB, ms,
          bytes / (ms * 1e-3) / 1e12, (int)hipGetLastError());
 }
 
@@ -285,11 +302,24 @@ int main(int argc, char** argv) {
     const size_t n = (size_t)ntiles * 17024;
     char *f, *u, *w, *fo;
     (void)hipMalloc(&f, n + 8192); (void)hipMalloc(&u, n + 8192); (void)hipMalloc(&w, n + 8192); (void)hipMalloc(&fo, n + 8192);
-    (void)hipMemset(f, 0, n); (void)hipMemset(u, 0, n); (void)hipMemset(w, 0, n); (void)hipMemset(fo, 0, n);
+    // pseudo-random contents by default (`./wave_stream zero`: all-zero arrays -- the chip then clocks
+    // higher and the rates flatter: DESIGN.md section 4.6)
+    if (argc > 1 && argv[1][0] == 'z') {
+      (void)hipMemset(f, 0, n); (void)hipMemset(u, 0, n); (void)hipMemset(w, 0, n); (void)hipMemset(fo, 0, n);
+    } else {
+      char* arr[4] = {f, u, w, fo};
+      for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (double*)arr[i], n / 8, 777ull + i);
+      (void)hipDeviceSynchronize();
+    }
     for (int rep = 0; rep < 2; ++rep) {
       run<0, 3, 4>(f, u, w, f, ntiles, ncol, chunkB, tileB, "plain");
       run<3, 3, 4, 2, 2>(f, u, w, f, ntiles, ncol, chunkB, tileB, "split OOB");
       run<5, 3, 4, 2, 2>(f, u, w, f, ntiles, ncol, chunkB, tileB, "splitEXEC");
+      run<5, 3, 4, 2, 2, 2, 6>(f, u, w, f, ntiles, ncol, chunkB, tileB, "safe wait");      // 2 in flight, stores not counted
+      run<5, 3, 4, 2, 2, 3, 12>(f, u, w, f, ntiles, ncol, chunkB, tileB, "safe wait");     // 3 in flight (the kernel)
+      run<5, 3, 4, 2, 2, 3, 16>(f, u, w, f, ntiles, ncol, chunkB, tileB, "3 ahead+st");    // 3 in flight, stores counted
+      run<5, 3, 4, 2, 0, 3, 12>(f, u, w, f, ntiles, ncol, chunkB, tileB, "safe,cached st");
+      run<5, 3, 4, 2, 0, 2, 6>(f, u, w, f, ntiles, ncol, chunkB, tileB, "safe,cached st");
       run<4, 3, 4, 2, 2>(f, u, w, f, ntiles, ncol, chunkB, 17024, "pair-line");   // 38*384 + 19*128 = 133 lines
       run<4, 3, 4, 0, 2>(f, u, w, f, ntiles, ncol, chunkB, 17024, "pair-line");
       run<4, 3, 4, 0, 0>(f, u, w, f, ntiles, ncol, chunkB, 17024, "pair-line");
