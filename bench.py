@@ -299,8 +299,11 @@ def free_bytes(torch):
 
 def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=None):
     """W untimed warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier +
-    synchronize; per-step HIP events on the launch stream.  Returns (max-over-ranks wall seconds,
-    per-step kernel ms)."""
+    synchronize, with ONE pair of HIP events on the launch stream around the K launches (kernel
+    time per step = elapsed / K: the kernels run back to back, nothing else is on the stream; an
+    event pair per step would put two marker packets between any two kernels and is kept out of
+    the timed region).  A second, untimed pass with an event pair per step gives the spread.
+    Returns (max-over-ranks wall seconds, [mean kernel ms per step] + per-step samples)."""
     if PREWARM_MS > 0 and prewarm_launch is not None:   # GPU wake-up (clock / power-state ramp)
         t_end = time.perf_counter() + PREWARM_MS * 1e-3
         while time.perf_counter() < t_end:
@@ -309,27 +312,43 @@ def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=Non
             torch.cuda.synchronize()
     for i in range(warmup):
         launch(-1 - i)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if world > 1:
         dist_mod.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    e0.record()
     for i in range(steps):
-        ev[i][0].record()
         launch(i)
-        ev[i][1].record()
+    e1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist_mod.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kms = [a.elapsed_time(b) for a, b in ev]
+    k_avg = e0.elapsed_time(e1) / steps
+    # spread: the same launches once more, one event pair each (not timed, not part of `value`)
+    ns = min(steps, 20)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ns)]
+    for i in range(ns):
+        ev[i][0].record()
+        launch(i)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    samples = [a.elapsed_time(b) for a, b in ev]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist_mod.get_backend() == "nccl" else "cpu")
         dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, kms
+    return dt, KernelTimes(k_avg, samples)
+
+
+class KernelTimes(list):
+    """per-step event samples (list) + the mean over the timed region (`avg`)"""
+    def __init__(self, avg, samples):
+        super().__init__(samples)
+        self.avg = avg
 
 
 def bench_plan(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup,
@@ -369,11 +388,16 @@ def bench_plan(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, s
     return dt, kms, info
 
 
+def kavg(kms):
+    return kms.avg if isinstance(kms, KernelTimes) else sum(kms) / len(kms)
+
+
 def roofline_block(alg_bytes, kms, extra=None):
-    k_avg = sum(kms) / len(kms)
+    k_avg = kavg(kms)
     ach = alg_bytes / (k_avg * 1e-3) / 1e9
     r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
          "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": k_avg,
+         "kernel_ms_note": "HIP events around the K timed launches / K; min / median: event pair per launch, separate pass",
          "kernel_ms_min": min(kms), "kernel_ms_median": statistics.median(kms)}
     if extra:
         r.update(extra)
@@ -472,7 +496,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": None if traffic is None else "profiles/hbm_traffic.json[%s]: PMC passes of "
                                   "tools/profile_round.sh on the builder's box, not measured in this run" % key,
-                "cell_updates_per_sec_kernel": n_loc * nx * (nz - 1) * ntr / (sum(kms) / len(kms) * 1e-3)}),
+                "cell_updates_per_sec_kernel": n_loc * nx * (nz - 1) * ntr / (kavg(kms) * 1e-3)}),
             "layout_conversion": {"import_ms_per_tracer_incl_fill": info["import_s_per_tracer"] * 1e3,
                                   "note": "reference layout -> plan layout, on the device, outside the timed region "
                                           "(like the reference's `!$acc update device`, :107)"},
@@ -497,7 +521,7 @@ def main():
                                       bsteps, bwarm, args.dist, npdt, tdt, mem_frac)
         if rank == 0:
             ab = M.algorithmic_bytes(n_loc, nx, nz, bt, f32=f32)
-            ka = sum(kms2) / len(kms2)
+            ka = kavg(kms2)
             key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t{bt}" + ("_f32" if f32 else "") + \
                   ("_wm" if info2["layout"].startswith("wave") else "")
             tr2 = traffic_lookup(key)
