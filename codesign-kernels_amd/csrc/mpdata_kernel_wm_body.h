@@ -54,7 +54,7 @@ namespace wm {
 
 // arithmetic helpers, DPP shifts and row stores of the x-march kernel
 using v2::dmax; using v2::dmin; using v2::rabs; using v2::rldexp; using v2::andiff; using v2::across;
-using v2::upwind; using v2::pp; using v2::pn; using v2::recip_nr; using v2::shift_dn;
+using v2::upwind; using v2::pp; using v2::pn; using v2::recip_nr; using v2::recip_const; using v2::shift_dn;
 using v2::shift_up; using v2::shift_dn_clamped; using v2::shift_up_clamped; using v2::Window;
 
 // Two tracers per wave (tracer batches): the tracer-dependent quantities of the column step are
@@ -375,9 +375,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     dma_pair(P);
   }
   __builtin_amdgcn_sched_barrier(0);
-  const R IRHO = R(1) / RHO;
-  const R IADZ = R(1) / adz_l;
-  const R IRHOW = R(1) / (rhow_l * adz_l);
+  const R IRHO = recip_const(RHO);
+  const R IADZ = recip_const(adz_l);
+  const R IRHOW = recip_const(rhow_l * adz_l);
 #ifdef MPDATA_FAST_DIV
   // FAST carries the second-pass fluxes DOUBLED (andiff's factor 0.5 is not applied: one
   // multiplication fewer per flux) and the limiter ratios HALVED (doubled denominators, clamp
