@@ -691,9 +691,13 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     MPDWM_PAIR(I2, I0, I1, I2, Full, q0 + 2, dma_f)
     MPDWM_PAIR(I1, I2, I2, I0, Full, q0 + 4, dma_f)
   }
-  for (; q0 <= q_last; q0 += 6) {  // drain
+  // drain.  Two tracers per wave: pairs beyond the last column are not run (+2 % at 25 tracers; the
+  // one-tracer forms have no register to spare for the extra exits and run them as empty steps)
+  for (; q0 <= q_last; q0 += 6) {
     MPDWM_PAIR(I0, I1, I0, I1, Part, q0, dma_p)
+    if constexpr (TPW == 2) if (q0 + 2 > q_last) break;
     MPDWM_PAIR(I2, I0, I1, I2, Part, q0 + 2, dma_p)
+    if constexpr (TPW == 2) if (q0 + 4 > q_last) break;
     MPDWM_PAIR(I1, I2, I2, I0, Part, q0 + 4, dma_p)
   }
 #undef MPDWM_PAIR
