@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) fill_random(double* a, size_t n, unsigned
 // MODE 0: 16-B DMA, one instruction per array and column PAIR (864 B), ring of NS pairs
 // MODE 1: 4-B DMA, two instructions per array and column (432 B), ring of NS columns
 // MODE 2: register loads (buffer_load_dwordx2 per lane), software pipeline depth NS columns
-template <int MODE, int NS, int WPB, int LA = 0, int SA = 0, int AH = NS - 1, int WN = 10>
+template <int MODE, int NS, int WPB, int LA = 0, int SA = 0, int AH = NS - 1, int WN = 10, int SB = 0>
 __global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, const char* w, char* fo,
                                                   int ntiles, int ncol, int chunkB, long long tileB, int tmap) {
   const int lane = threadIdx.x & 63;
@@ -247,9 +247,9 @@ __global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, 
       const double a1 = s[64 + kl] + s[128 + 64 + kl] + s[256 + 64 + kl];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)sA, (int)(p * 2 * mainB), SA);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)sB, (int)(p * 2 * remB), 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a0), ro, (int)sB, (int)(p * 2 * remB), SB);
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)sA, (int)((p * 2 + 1) * mainB), SA);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)sB, (int)((p * 2 + 1) * remB), 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a1), ro, (int)sB, (int)((p * 2 + 1) * remB), SB);
       dma(p + AH);
     }
   } else {
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(64 * WPB) skel3(const char* f, const char* u, 
   }
 }
 
-template <int MODE, int NS, int WPB, int LA = 0, int SA = 0, int AH = NS - 1, int WN = 10>
+template <int MODE, int NS, int WPB, int LA = 0, int SA = 0, int AH = NS - 1, int WN = 10, int SB = 0>
 void run(const char* f, const char* u, const char* w, char* fo, int ntiles, int ncol, int chunkB, long long tileB, const char* tag, int tmap = 0, int ldsper = 10240) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int blocks = (ntiles + WPB - 1) / WPB;
@@ -284,14 +284,14 @@ void run(const char* f, const char* u, const char* w, char* fo, int ntiles, int 
   const int stat = (MODE == 0 || MODE >= 3) ? NS * 3 * 1024 : MODE == 1 ? NS * 3 * 512 : 0;
   const int dyn = stat < ldsper ? WPB * (ldsper - stat) : 0;
   for (int r = 0; r < 60; ++r)
-    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA, AH, WN>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB, tmap);
+    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA, AH, WN, SB>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB, tmap);
   (void)hipEventRecord(e0);
   for (int r = 0; r < 60; ++r)
-    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA, AH, WN>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB, tmap);
+    hipLaunchKernelGGL((skel3<MODE, NS, WPB, LA, SA, AH, WN, SB>), dim3(blocks), dim3(64 * WPB), dyn, 0, f, u, w, fo, ntiles, ncol, chunkB, tileB, tmap);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 60;
   const double bytes = (double)ntiles * ncol * chunkB * 4;
-  printf("%-10s tmap %d lds/wave %d LA %d SA %d mode %d ring %d ahead %d wait %d waves/wg %d tileB %lld: %.3f ms  %.2f TB/s (err %d)\n", tag, tmap, ldsper, LA, SA, MODE, NS, AH, WN, WPB, tileB, ms,
+  printf("%-10s SB %d tmap %d lds/wave %d LA %d SA %d mode %d ring %d ahead %d wait %d waves/wg %d tileB %lld: %.3f ms  %.2f TB/s (err %d)\n", tag, SB, tmap, ldsper, LA, SA, MODE, NS, AH, WN, WPB, tileB, ms,
          bytes / (ms * 1e-3) / 1e12, (int)hipGetLastError());
 }
 
@@ -318,6 +318,9 @@ int main(int argc, char** argv) {
       run<5, 3, 4, 2, 2, 2, 6>(f, u, w, f, ntiles, ncol, chunkB, tileB, "safe wait");      // 2 in flight, stores not counted
       run<5, 3, 4, 2, 2, 3, 12>(f, u, w, f, ntiles, ncol, chunkB, tileB, "safe wait");     // 3 in flight (the kernel)
       run<5, 3, 4, 2, 2, 3, 16>(f, u, w, f, ntiles, ncol, chunkB, tileB, "3 ahead+st");    // 3 in flight, stores counted
+      run<5, 3, 4, 2, 2, 3, 12, 2>(f, u, w, f, ntiles, ncol, chunkB, tileB, "rem st nt");       // remainder stores streaming as well
+      run<5, 3, 4, 2, 2, 3, 12, 1>(f, u, w, f, ntiles, ncol, chunkB, tileB, "rem st sc0");
+      run<5, 3, 4, 2, 2, 3, 12, 16>(f, u, w, f, ntiles, ncol, chunkB, tileB, "rem st sc1");
       run<5, 3, 4, 2, 0, 3, 12>(f, u, w, f, ntiles, ncol, chunkB, tileB, "safe,cached st");
       run<5, 3, 4, 2, 0, 2, 6>(f, u, w, f, ntiles, ncol, chunkB, tileB, "safe,cached st");
       run<4, 3, 4, 2, 2>(f, u, w, f, ntiles, ncol, chunkB, 17024, "pair-line");   // 38*384 + 19*128 = 133 lines
