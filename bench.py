@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--batched-tracers", type=int, default=25)
     ap.add_argument("--batched-steps", type=int, default=20, help="timed steps of the 25-tracer block (at most --steps)")
     ap.add_argument("--no-scatter", action="store_true", help="N > 1: skip the scatter/gather measurement")
+    ap.add_argument("--no-host-call", action="store_true",
+                    help="skip the end-to-end block (the drop-in call on host arrays, PCIe-inclusive)")
     ap.add_argument("--no-reflayout", action="store_true",
                     help="skip the side measurement of the reference-layout device call (x-march kernel)")
     ap.add_argument("--layout", choices=["wavemajor", "reference"], default="wavemajor",
@@ -602,6 +604,32 @@ def main():
                     "value": cells_1 * s3 / dt3, "ms_per_step": dt3 / s3 * 1e3, "roofline": roofline_block(ab, kms3)}}
         del sh32
         torch.cuda.empty_cache()
+
+    # ---- end to end: the drop-in call on HOST arrays, H2D + kernel + D2H -- never
+    #      `value`; N = 1 only -------------------------------------------------------------------
+    if world == 1 and rank == 0 and not args.no_host_call and not f32 and ntr == 1:
+        try:
+            host = {}
+            for k in ("f", "u", "w", "rho", "rhow", "adz", "flux"):
+                t = alloc(sh[k], k)
+                M.fill_synthetic(t, k, 300, args.dist, ncrms_global=n_glob, sl0=sl0)
+                host[k] = t.cpu().numpy().T   # Fortran order, the reference's shapes (pageable memory)
+                del t
+            torch.cuda.empty_cache()
+            ts = []
+            for _ in range(3):   # (the first call also pays for the library's buffers)
+                t0 = time.perf_counter()
+                M.advect_scalar2D_host(host["f"], host["u"], host["w"], host["rho"], host["rhow"], host["flux"], host["adz"])
+                ts.append(time.perf_counter() - t0)
+            result["end_to_end_host_call"] = {
+                "workload": f"mpdata_advect_scalar2d on host arrays (pageable), ncrms={n_loc} nx={nx} nz={nz}, 1 tracer: "
+                            "H2D + kernel + D2H, chunked and pipelined (DESIGN.md 5b)",
+                "seconds_first_call": ts[0], "seconds": min(ts[1:]),
+                "value": cells_1 / min(ts[1:]), "unit": "cell-updates/s",
+                "note": "PCIe-inclusive; reported beside the device-resident `value`, never as it"}
+            del host
+        except Exception as exc:
+            result["end_to_end_host_call"] = {"error": repr(exc)}
 
     # ---- side measurement: the second / third kernel, rank 0 only ----------
     if not args.no_bwk and rank == 0 and not f32 and ntr == 1:
