@@ -691,14 +691,31 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     MPDWM_PAIR(I2, I0, I1, I2, Full, q0 + 2, dma_f)
     MPDWM_PAIR(I1, I2, I2, I0, Full, q0 + 4, dma_f)
   }
-  // drain.  Two tracers per wave: pairs beyond the last column are not run (+2 % at 25 tracers; the
-  // one-tracer forms have no register to spare for the extra exits and run them as empty steps)
-  for (; q0 <= q_last; q0 += 6) {
-    MPDWM_PAIR(I0, I1, I0, I1, Part, q0, dma_p)
-    if constexpr (TPW == 2) if (q0 + 2 > q_last) break;
-    MPDWM_PAIR(I2, I0, I1, I2, Part, q0 + 2, dma_p)
-    if constexpr (TPW == 2) if (q0 + 4 > q_last) break;
-    MPDWM_PAIR(I1, I2, I2, I0, Part, q0 + 4, dma_p)
+  // drain: pairs beyond the last column are not run (+2 % at 25 tracers).  The two forms of the
+  // same thing are what the register allocator accepts without spilling in either case.
+  if constexpr (TPW == 2) {
+    for (; q0 <= q_last; q0 += 6) {
+      MPDWM_PAIR(I0, I1, I0, I1, Part, q0, dma_p)
+      if (q0 + 2 > q_last) break;
+      MPDWM_PAIR(I2, I0, I1, I2, Part, q0 + 2, dma_p)
+      if (q0 + 4 > q_last) break;
+      MPDWM_PAIR(I1, I2, I2, I0, Part, q0 + 4, dma_p)
+    }
+  } else {
+    for (; q0 + 5 <= q_last; q0 += 6) {   // whole trips, then the pairs that are left (up to three:
+      MPDWM_PAIR(I0, I1, I0, I1, Part, q0, dma_p)   // five columns = two pairs and a half)
+      MPDWM_PAIR(I2, I0, I1, I2, Part, q0 + 2, dma_p)
+      MPDWM_PAIR(I1, I2, I2, I0, Part, q0 + 4, dma_p)
+    }
+    if (q0 <= q_last) {
+      MPDWM_PAIR(I0, I1, I0, I1, Part, q0, dma_p)
+      if (q0 + 2 <= q_last) {
+        MPDWM_PAIR(I2, I0, I1, I2, Part, q0 + 2, dma_p)
+        if (q0 + 4 <= q_last) {
+          MPDWM_PAIR(I1, I2, I2, I0, Part, q0 + 4, dma_p)
+        }
+      }
+    }
   }
 #undef MPDWM_PAIR
 #undef MPDWM_FLUSH_DEFERRED
