@@ -228,8 +228,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   //      compile-time offsets on top of these.  The raw inputs of the vertical neighbours are
   //      extra reads with the kb / kc clamps in the address.  Lanes above nzm (ghost level nz
   //      and dead lanes) read zeros for f, u and w -- element 63 of a column block is never
-  //      written with data (chunk <= 62; LPS = 64 selects w instead) and the ring is zeroed at
-  //      kernel start: with w = 0 the ghost level's fluxes are exact zeros, which is all the
+  //      written with data (chunk <= 62: the lane that fetches it is out of range and delivers
+  //      zeros with every pair; LPS = 64 selects w instead): with w = 0 the ghost level's fluxes are exact zeros, which is all the
   //      level below ever takes from it (www(:,:,:,nz) = 0, :511).
   const R* const p_own = my + ((LPS == 64 || lvl_ok) ? pos : 63);
   const R* const p_dn = my + (s_l * nzm + (kl > 0 ? kl - 1 : 0));
@@ -358,16 +358,17 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     }
   };
 
-  // ---- prologue: zero the ring (the never-fetched tails of the column blocks supply w = 0 of
-  //      the ghost level), then pairs 0, 1, 2 into flight, each behind two dropped column stores so
-  //      that the counted wait of the first pairs sees the steady-state op pattern
-#pragma unroll
+  // ---- prologue: pairs 0, 1, 2 into flight, each behind two dropped column stores so that the
+  //      counted wait of the first pairs sees the steady-state op pattern.  The ring needs no
+  //      initialisation: every fetch instruction group writes all 64 x 16 bytes of its array block
+  //      -- a lane that is out of range (the tail of a column block behind the chunk, a column
+  //      that does not exist for u or w) writes zeros --, so the tails that supply f = u = w = 0 of
+  //      the ghost level are (re)written with every pair.
 #ifdef MPDWM_ABL_NODMA  // timing ablation: arithmetic on (non-zero, finite) stand-in data
+#pragma unroll
   for (int j = 0; j < T::NS * T::SLOT / 64; ++j) my[j * 64 + lane] = R(0.25) + R(0.001) * R((j * 64 + lane) % 97) - R(0.3) * R(lane & 1);
-#else
-  for (int j = 0; j < T::NS * T::SLOT / 64; ++j) my[j * 64 + lane] = R(0);
-#endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
   for (int P = 0; P < T::NS; ++P) {
     st_col(false, 0, V(R(0)), std::integral_constant<int, 1>{});
