@@ -636,7 +636,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 
   // Six columns = three pairs per trip, so that the register-ring phase (c mod 3), the LDS slot
   // ((c/2) mod 3) and the column of the pair (c mod 2) are compile-time constants.
-  //   fill (q = -2 .. 3) and drain trips: wave-uniform conditions; steps beyond q = nx+3 do nothing;
+  //   fill (q = -2 .. 3) and drain: wave-uniform conditions; the drain ends with the pair that holds
+  //   column q = nx+3 (a step beyond it, the second of that pair for odd nx, does nothing);
   //   steady-state trips (4 <= q, q+5 <= nx): every stage active, no conditions.
   const int q_last = nx + 3;
   // per pair: wait for it (two newer pairs: STREAM 2 x 6 DMA instructions, else 2 x 3), two column steps,
