@@ -70,6 +70,13 @@ def parse():
                     help="skip the end-to-end block (the drop-in call on host arrays, PCIe-inclusive)")
     ap.add_argument("--no-reflayout", action="store_true",
                     help="skip the side measurement of the reference-layout device call (x-march kernel)")
+    ap.add_argument("--serpentine", action="store_true",
+                    help="serpentine tile order (DESIGN.md 4.6): off by default, only pays with --shared-uw")
+    ap.add_argument("--shared-uw", action="store_true",
+                    help="headline on ONE plan whose field sets share u, w (round-2 protocol); default: a plan per "
+                         "field set with its own u, w")
+    ap.add_argument("--no-fresh-uw", action="store_true", help="skip the step_with_fresh_uw side block")
+    ap.add_argument("--no-shared-block", action="store_true", help="skip the shared-u,w side block")
     ap.add_argument("--layout", choices=["wavemajor", "reference"], default="wavemajor",
                     help="device layout of the plans the headline runs on (include/mpdata_hip.h section 3)")
     return ap.parse_args()
@@ -357,41 +364,123 @@ class KernelTimes(list):
         self.avg = avg
 
 
-def bench_plan(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup,
-               dist_law, np_dtype, tdt, mem_frac=0.55):
-    """The hot path behind the plan API (device state in the library's own layout,
-    include/mpdata_hip.h section 3): one step = one run of `ntr` tracers on a field set of its
-    own.  As many pristine field sets as the steps need are created if they fit in `mem_frac` of
-    the free memory; otherwise the timed steps cycle through the sets (noted in the result)."""
-    eb = 8 if tdt == torch.float64 else 4
-    set_bytes = n_loc * (nx + 6) * (nz - 1) * eb * ntr
-    want = steps + min(warmup, N_SCRATCH)
-    nset = int(max(2, min(want, (free_bytes(torch) * mem_frac) // set_bytes)))
-    plan = M.Plan(n_loc, nx, nz, nset * ntr, dtype=np_dtype)
-    plan.set_stream()
-    plan.import_device(None, shared["u"], shared["w"], shared["rho"], shared["rhow"], shared["adz"], None)
-    ftmp = torch.empty(shape_f, dtype=tdt, device=dev)
-    t0 = time.perf_counter()
-    for t in range(nset * ntr):     # per-tracer / per-set seeds: distinct data, same law
-        M.fill_synthetic(ftmp, "f", 100 + t, dist_law, ncrms_global=n_glob, sl0=sl0)
-        plan.import_device(ftmp, flux=shared["flux"], first_tracer=t)
+MAX_COLD_SETS = 48   # distinct field sets the timed steps cycle through (each 1.6 GB at configs[2]: far past the 256-MB Infinity Cache)
+
+
+def _ev_ms(torch, fn, reps=1):
+    """milliseconds of fn() on the current stream (HIP events), mean of `reps` back-to-back calls"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    t_import = time.perf_counter() - t0
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def bench_plan(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup,
+               dist_law, np_dtype, tdt, mem_frac=0.55, shared_uw=False):
+    """The hot path behind the plan API (device state in the library's own layout,
+    include/mpdata_hip.h section 3): one step = one run of `ntr` tracers on a field set of its own.
+
+    shared_uw = False (the headline): every field set is a PLAN OF ITS OWN with its own f AND its own
+    u, w, rho, rhow, adz (same input law, per-set seed), so that no timed launch re-reads a byte the
+    previous launch touched -- the reference's timed region is one call on its own data (:109-110,
+    :237-239).  shared_uw = True: one plan, the field sets are tracers of it and share u, w (what
+    consecutive tracers of one CRM step look like; 1.05 of the 2.14 GB of a launch are then the
+    previous launch's bytes).  As many sets as the steps need are created if they fit in `mem_frac`
+    of the free memory (at most MAX_COLD_SETS distinct ones); otherwise the timed steps cycle."""
+    eb = 8 if tdt == torch.float64 else 4
+    f_bytes = n_loc * (nx + 6) * (nz - 1) * eb * ntr
+    uw_bytes = n_loc * ((nx + 5) * (nz - 1) + (nx + 4) * nz) * eb
+    set_bytes = f_bytes + (0 if shared_uw else int(1.1 * uw_bytes))
+    want = steps + min(warmup, N_SCRATCH)
+    if not shared_uw:
+        want = min(want, MAX_COLD_SETS)
+    nset = int(max(2, min(want, (free_bytes(torch) * mem_frac) // set_bytes)))
+    ftmp = torch.empty(shape_f, dtype=tdt, device=dev)
+    conv = {}
+    if shared_uw:
+        plan = M.Plan(n_loc, nx, nz, nset * ntr, dtype=np_dtype)
+        plan.set_stream()
+        plan.import_device(None, shared["u"], shared["w"], shared["rho"], shared["rhow"], shared["adz"], None)
+        for t in range(nset * ntr):     # per-tracer / per-set seeds: distinct data, same law
+            M.fill_synthetic(ftmp, "f", 100 + t, dist_law, ncrms_global=n_glob, sl0=sl0)
+            plan.import_device(ftmp, flux=shared["flux"], first_tracer=t)
+        plans = [plan]
+        run = lambda s: plan.run(s * ntr, ntr)
+    else:
+        plans = []
+        tmp = {k: torch.empty_like(shared[k]) for k in ("u", "w", "rho", "rhow", "adz")}
+        for sset in range(nset):
+            pl = M.Plan(n_loc, nx, nz, ntr, dtype=np_dtype)
+            pl.set_stream()
+            for k in tmp:
+                M.fill_synthetic(tmp[k], k, 100 + 7919 * (sset + 1), dist_law, ncrms_global=n_glob, sl0=sl0)
+            if sset == 0:   # layout-entry cost, measured on its own (no fill inside): u + w, then one tracer of f
+                pl.import_device(None, tmp["u"], tmp["w"], tmp["rho"], tmp["rhow"], tmp["adz"], None)
+                conv["import_ms_u_and_w"] = _ev_ms(torch, lambda: pl.import_device(None, tmp["u"], tmp["w"]), 3)
+            pl.import_device(None, tmp["u"], tmp["w"], tmp["rho"], tmp["rhow"], tmp["adz"], None)
+            for t in range(ntr):
+                M.fill_synthetic(ftmp, "f", 100 + sset * ntr + t, dist_law, ncrms_global=n_glob, sl0=sl0)
+                pl.import_device(ftmp, flux=shared["flux"], first_tracer=t)
+            if sset == 0:
+                conv["import_ms_f_per_tracer"] = _ev_ms(torch, lambda: pl.import_device(ftmp, first_tracer=ntr - 1), 3)
+                conv["export_ms_f_per_tracer"] = _ev_ms(torch, lambda: pl.export_device(ftmp, first_tracer=ntr - 1), 3)
+                conv["bytes_per_array"] = int(ftmp.numel() * eb)
+                pl.import_device(ftmp, first_tracer=ntr - 1)   # (the export wrote into ftmp: same values back)
+            plans.append(pl)
+        del tmp
+        run = lambda s: plans[s].run()
+    torch.cuda.synchronize()
     del ftmp
     nscr = min(max(warmup, 1), N_SCRATCH, nset - 1)
     ntimed = nset - nscr
 
     def launch(i):
         s = (nset - 1 - ((-1 - i) % nscr)) if i < 0 else (i % ntimed)   # warm-up: the scratch sets
-        plan.run(s * ntr, ntr)
+        run(s)
 
     dt, kms = timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=lambda: launch(-1))
-    info = {"layout": "wave-major (plan-private)" if plan.layout == M.LAYOUT_WAVEMAJOR else "reference",
-            "field_sets": ntimed, "steps_per_field_set": -(-steps // ntimed),
-            "import_s_per_tracer": t_import / (nset * ntr)}
-    plan.close()
+    info = {"layout": "wave-major (plan-private)" if plans[0].layout == M.LAYOUT_WAVEMAJOR else "reference",
+            "field_sets": ntimed, "steps_per_field_set": -(-steps // ntimed), "uw_shared_across_steps": bool(shared_uw),
+            "conversion": conv}
+    for pl in plans:
+        pl.close()
     torch.cuda.empty_cache()
     return dt, kms, info
+
+
+def bench_fresh_uw(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, steps, warmup,
+                   dist_law, np_dtype, tdt, nsets=16):
+    """One step = mpdata_plan_run_uw(plan, u, w) with u, w in the REFERENCE layout on the device,
+    distinct arrays for consecutive steps (a set = a plan with its own f + its own reference-layout
+    u, w: 2.7 GB, the steps cycle through `nsets` of them)."""
+    sets = []
+    ftmp = torch.empty(shape_f, dtype=tdt, device=dev)
+    for s_ in range(nsets):
+        pl = M.Plan(n_loc, nx, nz, 1, dtype=np_dtype)
+        pl.set_stream()
+        u = torch.empty_like(shared["u"]); w = torch.empty_like(shared["w"])
+        M.fill_synthetic(u, "u", 500 + 31 * s_, dist_law, ncrms_global=n_glob, sl0=sl0)
+        M.fill_synthetic(w, "w", 500 + 31 * s_, dist_law, ncrms_global=n_glob, sl0=sl0)
+        M.fill_synthetic(ftmp, "f", 500 + s_, dist_law, ncrms_global=n_glob, sl0=sl0)
+        pl.import_device(ftmp, u, w, shared["rho"], shared["rhow"], shared["adz"], shared["flux"])
+        sets.append((pl, u, w))
+    del ftmp
+    nscr = 2
+
+    def launch(i):
+        pl, u, w = sets[(nsets - 1 - ((-1 - i) % nscr)) if i < 0 else (i % (nsets - nscr))]
+        pl.run_uw(u, w)
+
+    dt, kms = timed_loop(torch, dist_mod, world, launch, steps, warmup)
+    for pl, _, _ in sets:
+        pl.close()
+    del sets
+    torch.cuda.empty_cache()
+    return dt, kms, nsets - nscr
 
 
 def kavg(kms):
@@ -456,6 +545,8 @@ def main():
 
     M.set_variant(M.VARIANT_FAST if args.variant == "fast" else M.VARIANT_EXACT)
     M.set_tile(args.tile)
+    serp = 1 if args.serpentine else 0
+    M.set_serpentine(serp)
     if args.layout == "reference":
         M.set_plan_layout(M.LAYOUT_REFERENCE)
     nx, nz = args.nx, args.nz
@@ -475,7 +566,7 @@ def main():
 
     # ---- headline: configs[2] per GPU through the plan API -----------------------------------
     dt, kms, info = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, ntr, steps,
-                               warmup, args.dist, npdt, tdt, mem_frac)
+                               warmup, args.dist, npdt, tdt, mem_frac, shared_uw=args.shared_uw)
     value = cells_1 * ntr * steps / dt
     alg_bytes = M.algorithmic_bytes(n_loc, nx, nz, ntr, f32=f32)  # per launch (one GPU)
 
@@ -496,6 +587,11 @@ def main():
                        "ntracers": ntr, "variant": args.variant, "input_law": args.dist,
                        "device_layout": info["layout"], "field_sets": info["field_sets"],
                        "steps_per_field_set": info["steps_per_field_set"],
+                       "uw_shared_across_steps": info["uw_shared_across_steps"],
+                       "serpentine": bool(serp),
+                       "cold": "every timed step runs on a plan of its own: own f, u, w, rho, rhow, adz (no byte of a "
+                               "launch was touched by the previous one)" if not info["uw_shared_across_steps"] else
+                               "NO: the field sets share u, w",
                        "prewarm_ms": args.prewarm_ms,
                        "parallelism": f"ncrms-sharded x{world}, no data-path collective"},
             "roofline": roofline_block(alg_bytes, kms, {
@@ -503,9 +599,10 @@ def main():
                 "traffic_source": None if traffic is None else "profiles/hbm_traffic.json[%s]: PMC passes of "
                                   "tools/profile_round.sh on the builder's box, not measured in this run" % key,
                 "cell_updates_per_sec_kernel": n_loc * nx * (nz - 1) * ntr / (kavg(kms) * 1e-3)}),
-            "layout_conversion": {"import_ms_per_tracer_incl_fill": info["import_s_per_tracer"] * 1e3,
-                                  "note": "reference layout -> plan layout, on the device, outside the timed region "
-                                          "(like the reference's `!$acc update device`, :107)"},
+            "layout_conversion": dict(info["conversion"], note=
+                                      "reference layout <-> plan layout on the device (HIP events, no fill inside), "
+                                      "outside the timed region of the headline like the reference's `!$acc update "
+                                      "device`, :107; `step_with_fresh_uw` charges it"),
         }
         try:
             result["roofline"]["measured_copy_GBs"] = copy_ceiling(torch, dev)
@@ -518,6 +615,35 @@ def main():
             result["roofline"]["frac_of_measured_ceiling"] = result["roofline"]["achieved"] / max(plain, nt)
         except Exception:
             result["roofline"]["measured_stream_3r1w_GBs"] = None
+
+    # ---- side block: the round-2 protocol (ONE plan, the field sets share u, w, serpentine tile
+    #      order on): what consecutive tracers of one CRM step get ------------------------------
+    if not args.no_shared_block and not args.shared_uw and ntr == 1:
+        M.set_serpentine(1)
+        ssteps = min(steps, 40)
+        dt6, kms6, info6 = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, 1, ssteps,
+                                      min(warmup, SIDE_WARMUP), args.dist, npdt, tdt, 0.3 * mem_frac, shared_uw=True)
+        M.set_serpentine(serp)
+        if rank == 0:
+            result["consecutive_tracers_shared_uw"] = {
+                "workload": "the headline workload with u, w SHARED by all timed launches (one plan, the field sets are "
+                            "its tracers) and the serpentine tile order on: 1.05 of the 2.14 GB of a launch are the "
+                            "previous launch's bytes, part of them still in the Infinity Cache -- NOT a cold call",
+                "value": cells_1 * ssteps / dt6, "unit": "cell-updates/s", "steps": ssteps,
+                "ms_per_step": dt6 / ssteps * 1e3, "roofline": roofline_block(alg_bytes, kms6)}
+
+    # ---- side block: one step on FRESH reference-layout u, w (mpdata_plan_run_uw): the layout
+    #      entry of the velocities is inside the timed region, every step ----------------------
+    if not args.no_fresh_uw and ntr == 1 and not f32:
+        fsteps = min(steps, 40)
+        dt7, kms7, nfs = bench_fresh_uw(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, fsteps,
+                                        min(warmup, SIDE_WARMUP), args.dist, npdt, tdt)
+        if rank == 0:
+            result["step_with_fresh_uw"] = {
+                "workload": f"mpdata_plan_run_uw: f resident in the plan layout, u and w handed over as reference-layout "
+                            f"device arrays EVERY step (distinct arrays per step, {nfs} sets), ncrms={n_loc}/GPU, 1 tracer",
+                "value": cells_1 * fsteps / dt7, "unit": "cell-updates/s", "steps": fsteps,
+                "ms_per_step": dt7 / fsteps * 1e3, "roofline": roofline_block(alg_bytes, kms7)}
 
     # ---- BASELINE configs[3] / [4]: 25 tracers per instance, every rank ---------------------
     if not args.no_batched and ntr == 1:

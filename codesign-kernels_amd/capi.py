@@ -73,6 +73,8 @@ def lib():
         L.mpdata_plan_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         L.mpdata_plan_run_tracers.restype = ci
         L.mpdata_plan_run_tracers.argtypes = [vp, ci, ci]
+        L.mpdata_plan_run_uw.restype = ci
+        L.mpdata_plan_run_uw.argtypes = [vp, ci, ci, vp, vp]
         L.mpdata_plan_import_device.restype = ci
         L.mpdata_plan_import_device.argtypes = [vp] + [vp] * 7 + [ci, ci]
         L.mpdata_plan_export_device.restype = ci
@@ -124,6 +126,10 @@ def lib():
         L.mpdata_set_variant.restype = ci
         L.mpdata_set_variant.argtypes = [ci]
         L.mpdata_get_variant.restype = ci
+        L.mpdata_set_serpentine.restype = ci
+        L.mpdata_set_serpentine.argtypes = [ci]
+        L.mpdata_set_wm_flags.restype = ci
+        L.mpdata_set_wm_flags.argtypes = [ci]
         L.mpdata_set_tile.restype = ci
         L.mpdata_set_tile.argtypes = [ci]
         L.mpdata_set_debug_buffer.restype = ci
@@ -150,6 +156,23 @@ def set_variant(v):
 
 def get_variant():
     return lib().mpdata_get_variant()
+
+
+WMF_NOSTREAM, WMF_TPW1, WMF_NOSPLIT = 1, 2, 4
+
+
+def set_serpentine(on):
+    """Serpentine tile order of wave-major plans (include/mpdata_hip.h section 8); returns the previous setting."""
+    return lib().mpdata_set_serpentine(int(on))
+
+
+def set_wm_flags(flags):
+    """Test switches of the wave-major launch (WMF_*; < 0 queries); returns the previous value."""
+    return lib().mpdata_set_wm_flags(int(flags))
+
+
+def version():
+    return lib().mpdata_version().decode()
 
 
 def set_tile(t):
@@ -404,6 +427,14 @@ class Plan:
             _check(lib().mpdata_plan_run(self._p))
         else:
             _check(lib().mpdata_plan_run_tracers(self._p, int(first_tracer), int(1 if ntracers is None else ntracers)))
+
+    def run_uw(self, u, w, first_tracer=0, ntracers=None):
+        """One step on fresh velocities: u, w = reference-layout DEVICE tensors (reversed-axes torch
+        layout), f and the rest stay in the plan (mpdata_plan_run_uw)."""
+        ncrms, nx, nz, nt = self.dims
+        sh = shapes(ncrms, nx, nz, 1)
+        pu, pw = _dev_ptr(u, sh["u"], "u", self._tdt()), _dev_ptr(w, sh["w"], "w", self._tdt())
+        _check(lib().mpdata_plan_run_uw(self._p, int(first_tracer), int(nt - first_tracer if ntracers is None else ntracers), pu, pw))
 
     def sync(self):
         _check(lib().mpdata_plan_sync(self._p))

@@ -44,6 +44,10 @@ struct MpdataWmArgsT {
   int reverse;             // walk the tiles from the last to the first
 };
 typedef MpdataWmArgsT<double> MpdataWmArgs;
+// test switches of the wave-major launch (mpdata_set_wm_flags; MPDATA_WM_NOSTREAM / _TPW1 / _NOSPLIT)
+#define MPDATA_WMF_NOSTREAM 1   // run the batch form of the kernel on a single tracer as well
+#define MPDATA_WMF_TPW1 2       // tracer batches: one tracer per wave
+#define MPDATA_WMF_NOSPLIT 4    // an odd last tracer stays in the two-tracer launch
 
 // One tiling of the kernel template (W columns per thread, SPW strips per
 // wave, NWV waves per workgroup).

@@ -22,12 +22,14 @@
 #include "mpdata_multi.h"
 
 namespace mpdata_exact {
+const char* build_flags();
 int max_tile_id();
 bool tile_info(int id, MpdataTileInfo* info);
 bool launch(int id, const MpdataArgs& a, int ntracers, void* stream);
 bool launch_f32(int id, const MpdataArgsF32& a, int ntracers, void* stream);
 }  // namespace mpdata_exact
 namespace mpdata_fast {
+const char* build_flags();
 int max_tile_id();
 bool tile_info(int id, MpdataTileInfo* info);
 bool launch(int id, const MpdataArgs& a, int ntracers, void* stream);
@@ -228,14 +230,15 @@ void arena_free(Arena& a) {
   a = Arena();
 }
 
+// var: MPDATA_VARIANT_* (a plan passes the variant it was created with; < 0: the global one)
 template <typename R>
 int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u, const R* w,
-                  const R* rho, const R* rhow, const R* adz, R* flux, void* stream) {
+                  const R* rho, const R* rhow, const R* adz, R* flux, void* stream, int var = -1) {
   int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
   if (!f || !u || !w || !rho || !rhow || !adz || !flux)
     return set_err(MPDATA_EINVAL, "null array pointer");
-  const int var = variant();
+  if (var < 0) var = variant();
   MpdataTileInfo t;
   rc = choose_tile(var, ncrms, nx, nz, &t, (int)sizeof(R));
   if (rc) return rc;
@@ -306,12 +309,12 @@ int mpdata_advect_scalar2d_f32_device(int64_t ncrms, int nx, int nz, int ntracer
 // mpdata_kernel_wm_body.h and convert in upload / download / import / export; other plans
 // (fp32; nz > 64) keep the reference layout and run the x-/k-marching kernels.
 namespace mpdata_exact {
-bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream);
-bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream);
+bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
+bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
 }
 namespace mpdata_fast {
-bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream);
-bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream);
+bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
+bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
 }
 
 namespace {
@@ -323,13 +326,26 @@ int plan_layout_default() {
   }
   return g_layout;
 }
+// Serpentine tile order (every other run of a plan walks the tiles from the other end, so that it
+// starts on what the previous run left in the Infinity Cache): OFF by default -- it only pays when
+// consecutive runs of a plan share u, w (consecutive tracers of one CRM step), and a timing that
+// inherits cache state from the previous call is not the timing of a call.  MPDATA_SERPENTINE=1 or
+// mpdata_set_serpentine(1) turns it on.
+int g_serpentine = -1;
 int serpentine() {
-  static int v = -1;
-  if (v < 0) {
+  if (g_serpentine < 0) {
     const char* e = getenv("MPDATA_SERPENTINE");
-    v = (e && atoi(e) == 0) ? 0 : 1;
+    g_serpentine = (e && atoi(e) != 0) ? 1 : 0;
   }
-  return v;
+  return g_serpentine;
+}
+// test switches of the wave-major launch (MPDATA_WMF_*): from the environment once, or set
+int g_wm_flags = -1;
+int wm_flags() {
+  if (g_wm_flags < 0)
+    g_wm_flags = (getenv("MPDATA_WM_NOSTREAM") ? MPDATA_WMF_NOSTREAM : 0) | (getenv("MPDATA_WM_TPW1") ? MPDATA_WMF_TPW1 : 0) |
+                 (getenv("MPDATA_WM_NOSPLIT") ? MPDATA_WMF_NOSPLIT : 0);
+  return g_wm_flags;
 }
 int wm_wpb() { return 4; }  // waves (tiles) per workgroup of the wave-major kernels
 struct DevGuard {
@@ -417,6 +433,15 @@ int tracer_range(const mpdata_plan* p, int first, int count) {
   return 0;
 }
 
+// The reference-layout staging buffer of a wave-major plan (one tracer of f, or u / w): only host
+// transfers need it, so it is allocated by the first of them (a plan that is only ever fed from
+// device arrays -- bench.py keeps one per field set -- never pays its 538 MB).
+int plan_stage(mpdata_plan* p) {
+  if (p->stage) return 0;
+  HIP_TRY(hipMalloc(&p->stage, p->stage_elems * p->eb));
+  return 0;
+}
+
 // Arrays in the reference layout -> the plan.  `dev` says where the pointers live.  Null
 // pointers are skipped (the plan keeps what it has).  f / flux cover `count` tracers.
 int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, const void* rho,
@@ -436,6 +461,10 @@ int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, con
   }
   // wave-major: device sources are converted in place, host sources go through the staging
   // buffer one array (one tracer of f) at a time
+  if (!dev) {
+    const int rs = plan_stage(p);
+    if (rs) return rs;
+  }
   auto one = [&](int which, const void* src, size_t elems, int tr) -> int {
     void* ref = const_cast<void*>(src);
     if (!dev) {
@@ -481,6 +510,8 @@ int plan_export(mpdata_plan* p, void* f, void* flux, int first, int count, bool 
     if (dev) {
       HIP_TRY(mpdata_layout_convert(wm_job(p, 0, f, first, count), 8, false, p->stream));
     } else {
+      const int rs = plan_stage(p);
+      if (rs) return rs;
       for (int t = 0; t < count; ++t) {
         HIP_TRY(mpdata_layout_convert(wm_job(p, 0, p->stage, first + t, 1), 8, false, p->stream));
         HIP_TRY(hipMemcpyAsync((char*)f + (size_t)t * f1 * eb, p->stage, f1 * eb, hipMemcpyDeviceToHost, p->stream));
@@ -526,6 +557,7 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
     const size_t nb[7] = {p->sz.f * eb, p->sz.u * eb, p->sz.w * eb, p->sz.k * eb, p->sz.kz * eb, p->sz.k * eb,
                           p->sz.kz * ntracers * eb};
     e = arena_alloc(p->arena, nb);
+    if (e == hipSuccess) e = hipMemset(p->arena.p[6], 0, nb[6]);
     if (e == hipSuccess) {
       p->f = p->arena.p[0]; p->u = p->arena.p[1]; p->w = p->arena.p[2]; p->rho = p->arena.p[3];
       p->rhow = p->arena.p[4]; p->adz = p->arena.p[5]; p->flux = p->arena.p[6];
@@ -553,8 +585,10 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
     if (e == hipSuccess) e = hipMalloc(&p->pw, tile_arr);
     if (e == hipSuccess) e = hipMalloc(&p->pkc, (size_t)p->ntiles * 3 * p->chunk * web);
     if (e == hipSuccess) e = hipMalloc(&p->pflux, (size_t)p->ntiles * p->chunk * ntracers * web);
-    if (e == hipSuccess) e = hipMalloc(&p->stage, p->stage_elems * eb);
     if (e == hipSuccess) e = hipMalloc(&p->flux_ref, p->sz.kz * ntracers * eb);
+    // flux: level nz and tracers that are never run export what was imported -- or zeros
+    if (e == hipSuccess) e = hipMemset(p->flux_ref, 0, p->sz.kz * ntracers * eb);
+    if (e == hipSuccess) e = hipMemset(p->pflux, 0, (size_t)p->ntiles * p->chunk * ntracers * web);
     // u, w have column slots that nothing ever fills or fetches (c = 0; c = nx+5 of w)
     if (e == hipSuccess) e = hipMemset(p->pu, 0, tile_arr);
     if (e == hipSuccess) e = hipMemset(p->pw, 0, tile_arr);
@@ -637,6 +671,42 @@ int mpdata_plan_export_device(mpdata_plan* p, void* f, void* flux, int first_tra
   return plan_export(p, f, flux, first_tracer, ntracers, true);
 }
 
+// the kernel launch(es) of one run of a single-device plan, on the plan's stream
+static int plan_launch(mpdata_plan* p, int first, int count) {
+  int rc = 0;
+  if (p->layout == MPDATA_LAYOUT_WAVEMAJOR) {
+    MpdataWmArgs a;
+    a.f = (double*)p->pf + (long long)first * p->ntiles * p->tile_elems;
+    a.u = (const double*)p->pu; a.w = (const double*)p->pw; a.kc = (const double*)p->pkc;
+    a.flux = (double*)p->pflux + (long long)first * p->ntiles * p->chunk;
+    a.ntiles = p->ntiles; a.nx = p->nx; a.nz = p->nz; a.ntracers = count;
+    a.tile_elems = p->tile_elems;
+    a.f_tstride = (long long)p->ntiles * p->tile_elems;
+    a.flux_tstride = (long long)p->ntiles * p->chunk;
+    a.reverse = serpentine() ? (int)(p->runs++ & 1u) : 0;
+    const bool fast = p->variant == MPDATA_VARIANT_FAST;
+    const int fl = wm_flags();
+    const bool ok = p->eb == 8 ? (fast ? mpdata_fast::launch_wm(p->lps, p->wpb, a, (void*)p->stream, fl)
+                                       : mpdata_exact::launch_wm(p->lps, p->wpb, a, (void*)p->stream, fl))
+                               : (fast ? mpdata_fast::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream, fl)
+                                       : mpdata_exact::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream, fl));
+    if (!ok) return set_err(MPDATA_EINVAL, "wave-major kernel LPS=%d WPB=%d not instantiated", p->lps, p->wpb);
+    HIP_TRY(hipGetLastError());
+  } else {
+    const size_t f1 = p->sz.f / p->ntracers;
+    // (the plan's own variant, passed explicitly: the global one may be changed by other threads)
+    if (p->eb == 8)
+      rc = advect_device<double>(p->ncrms, p->nx, p->nz, count, (double*)p->f + first * f1, (const double*)p->u,
+                                 (const double*)p->w, (const double*)p->rho, (const double*)p->rhow,
+                                 (const double*)p->adz, (double*)p->flux + first * p->sz.kz, (void*)p->stream, p->variant);
+    else
+      rc = advect_device<float>(p->ncrms, p->nx, p->nz, count, (float*)p->f + first * f1, (const float*)p->u,
+                                (const float*)p->w, (const float*)p->rho, (const float*)p->rhow,
+                                (const float*)p->adz, (float*)p->flux + first * p->sz.kz, (void*)p->stream, p->variant);
+    if (rc) return rc;
+  }
+  return 0;
+}
 int mpdata_plan_run_tracers(mpdata_plan* p, int first, int count) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
   int rc = tracer_range(p, first, count);
@@ -649,38 +719,8 @@ int mpdata_plan_run_tracers(mpdata_plan* p, int first, int count) {
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run before mpdata_plan_upload");
   DevGuard g(p->device);
   HIP_TRY(hipEventRecord(p->ev0, p->stream));
-  if (p->layout == MPDATA_LAYOUT_WAVEMAJOR) {
-    MpdataWmArgs a;
-    a.f = (double*)p->pf + (long long)first * p->ntiles * p->tile_elems;
-    a.u = (const double*)p->pu; a.w = (const double*)p->pw; a.kc = (const double*)p->pkc;
-    a.flux = (double*)p->pflux + (long long)first * p->ntiles * p->chunk;
-    a.ntiles = p->ntiles; a.nx = p->nx; a.nz = p->nz; a.ntracers = count;
-    a.tile_elems = p->tile_elems;
-    a.f_tstride = (long long)p->ntiles * p->tile_elems;
-    a.flux_tstride = (long long)p->ntiles * p->chunk;
-    a.reverse = serpentine() ? (int)(p->runs++ & 1u) : 0;
-    const bool fast = p->variant == MPDATA_VARIANT_FAST;
-    const bool ok = p->eb == 8 ? (fast ? mpdata_fast::launch_wm(p->lps, p->wpb, a, (void*)p->stream)
-                                       : mpdata_exact::launch_wm(p->lps, p->wpb, a, (void*)p->stream))
-                               : (fast ? mpdata_fast::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream)
-                                       : mpdata_exact::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream));
-    if (!ok) return set_err(MPDATA_EINVAL, "wave-major kernel LPS=%d WPB=%d not instantiated", p->lps, p->wpb);
-    HIP_TRY(hipGetLastError());
-  } else {
-    const size_t f1 = p->sz.f / p->ntracers;
-    const int var_prev = variant();
-    g_variant = p->variant;
-    if (p->eb == 8)
-      rc = mpdata_advect_scalar2d_device(p->ncrms, p->nx, p->nz, count, (double*)p->f + first * f1, (const double*)p->u,
-                                         (const double*)p->w, (const double*)p->rho, (const double*)p->rhow,
-                                         (const double*)p->adz, (double*)p->flux + first * p->sz.kz, (void*)p->stream);
-    else
-      rc = mpdata_advect_scalar2d_f32_device(p->ncrms, p->nx, p->nz, count, (float*)p->f + first * f1, (const float*)p->u,
-                                             (const float*)p->w, (const float*)p->rho, (const float*)p->rhow,
-                                             (const float*)p->adz, (float*)p->flux + first * p->sz.kz, (void*)p->stream);
-    g_variant = var_prev;
-    if (rc) return rc;
-  }
+  rc = plan_launch(p, first, count);
+  if (rc) return rc;
   HIP_TRY(hipEventRecord(p->ev1, p->stream));
   p->ran = true;
   return 0;
@@ -688,6 +728,27 @@ int mpdata_plan_run_tracers(mpdata_plan* p, int first, int count) {
 int mpdata_plan_run(mpdata_plan* p) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
   return mpdata_plan_run_tracers(p, 0, p->ntracers);
+}
+
+// One step on FRESH velocities: u, w are reference-layout device arrays (what a CRM whose state
+// lives on the device hands over every step, reference :107 `update device` then kernels), f stays
+// in the plan.  The layout entry of u, w is part of the call (and of its event time).
+int mpdata_plan_run_uw(mpdata_plan* p, int first, int count, const void* u, const void* w) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (!u || !w) return set_err(MPDATA_EINVAL, "null array pointer");
+  if (p->multi) return set_err(MPDATA_EUNSUPPORTED, "mpdata_plan_run_uw on a multi-GPU plan: use the shard plans");
+  int rc = tracer_range(p, first, count);
+  if (rc) return rc;
+  if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run_uw before upload / import");
+  DevGuard g(p->device);
+  HIP_TRY(hipEventRecord(p->ev0, p->stream));
+  rc = plan_import(p, nullptr, u, w, nullptr, nullptr, nullptr, nullptr, 0, 1, true);
+  if (rc) return rc;
+  rc = plan_launch(p, first, count);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(p->ev1, p->stream));
+  p->ran = true;
+  return 0;
 }
 
 int mpdata_plan_sync(mpdata_plan* p) {
@@ -701,8 +762,12 @@ int mpdata_plan_sync(mpdata_plan* p) {
 static int plan_download(mpdata_plan* p, void* f, void* flux, int eb) {
   int rc = plan_check(p, eb);
   if (rc) return rc;
+  if (p->multi) {   // (the shards may have been filled directly: mpdata_plan_shard_plan + import)
+    for (int g = 0; g < mpdata_multi_ngpus(p->multi); ++g)
+      if (!mpdata_multi_sub(p->multi, g)->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_download before upload (shard %d)", g);
+    return mpdata_multi_download(p->multi, f, flux);
+  }
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_download before upload");
-  if (p->multi) return mpdata_multi_download(p->multi, f, flux);
   DevGuard g(p->device);
   rc = plan_export(p, f, flux, 0, p->ntracers, false);
   if (rc) return rc;
@@ -1037,6 +1102,16 @@ int mpdata_set_variant(int v) {
   return prev;
 }
 int mpdata_get_variant(void) { return variant(); }
+int mpdata_set_wm_flags(int flags) {
+  const int prev = wm_flags();
+  if (flags >= 0) g_wm_flags = flags & (MPDATA_WMF_NOSTREAM | MPDATA_WMF_TPW1 | MPDATA_WMF_NOSPLIT);
+  return prev;
+}
+int mpdata_set_serpentine(int on) {
+  const int prev = serpentine();
+  if (on == 0 || on == 1) g_serpentine = on;
+  return prev;
+}
 int mpdata_set_tile(int tile) {
   const int prev = tile_override();
   g_tile = tile < 0 ? -1 : tile;
@@ -1062,6 +1137,16 @@ int64_t mpdata_algorithmic_bytes_f32(int64_t ncrms, int nx, int nz, int ntracers
   return mpdata_algorithmic_bytes(ncrms, nx, nz, ntracers) / 2;
 }
 const char* mpdata_last_error(void) { return g_err.c_str(); }
-const char* mpdata_version(void) { return "mpdata-hip 0.1 (gfx950)"; }
+// The version string names every timing-ablation / experiment macro the kernels were compiled with
+// (mpdata_kernels_inst.h: build_flags); a shipped library has none, tests/test_capi_abi.py checks.
+const char* mpdata_version(void) {
+  static std::string v;
+  if (v.empty()) {
+    const char* fe = mpdata_exact::build_flags();
+    const char* ff = mpdata_fast::build_flags();
+    v = std::string("mpdata-hip 0.3 (gfx950) exact[") + fe + "] fast[" + ff + "]";
+  }
+  return v.c_str();
+}
 
 }  // extern "C"

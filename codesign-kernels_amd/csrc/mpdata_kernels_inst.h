@@ -74,11 +74,13 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
 // WPB = waves per workgroup.  Returns false if (lps, wpb) is not instantiated.
 #define MPDATA_WM_LPS(X) X(8) X(16) X(32) X(64)
 template <typename R, int LPS, int WPB>
-static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream) {
+static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
   // ntracers == 1: wave = tile in dispatch order, u and w streamed; else the per-XCD tracer walk with
   // u, w kept in L2 (see the kernel)
   // MPDATA_WM_NOSTREAM (tests): run the batch form of the kernel on a single tracer as well
-  const bool no_stream = getenv("MPDATA_WM_NOSTREAM") != nullptr;
+  // flags: MPDATA_WMF_* test switches (mpdata_args.h; mpdata_set_wm_flags / the MPDATA_WM_*
+  // environment variables, read once by the C-ABI layer -- not in this timed launch path)
+  const bool no_stream = flags & MPDATA_WMF_NOSTREAM, tpw1 = flags & MPDATA_WMF_TPW1, no_split = flags & MPDATA_WMF_NOSPLIT;
   if (a.ntracers == 1 && no_stream) {
     const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);
     hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false>), dim3(blocks), dim3(64 * WPB), 0,
@@ -87,7 +89,7 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream) {
     const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);
     hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, true>), dim3(blocks), dim3(64 * WPB), 0,
                        (hipStream_t)stream, a);
-  } else if (getenv("MPDATA_WM_TPW1") != nullptr) {   // (tests / A-B: one tracer per wave)
+  } else if (tpw1) {   // (tests / A-B: one tracer per wave)
     const long long per_xcd = ((long long)(a.ntiles + 7) / 8) * a.ntracers;  // waves of one XCD
     const unsigned blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
     hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false>), dim3(blocks), dim3(64 * WPB), 0,
@@ -97,7 +99,7 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream) {
     // of the batch kernel with an empty second half costs as much as a full one: 4 % at 25
     // tracers).  MPDATA_WM_NOSPLIT (tests): keep it in the batch launch.
     MpdataWmArgsT<R> b = a;
-    const bool split = (a.ntracers & 1) && getenv("MPDATA_WM_NOSPLIT") == nullptr;
+    const bool split = (a.ntracers & 1) && !no_split;
     if (split) b.ntracers = a.ntracers - 1;
     const long long per_xcd = ((long long)(b.ntiles + 7) / 8) * ((b.ntracers + 1) / 2);
     const unsigned blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
@@ -114,11 +116,11 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream) {
     }
   }
 }
-bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream) {
+bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags) {
   if (wpb != 4) return false;
 #define X(LPS_)                             \
   if (lps == LPS_) {                        \
-    launch_wm_t<double, LPS_, 4>(a, stream); \
+    launch_wm_t<double, LPS_, 4>(a, stream, flags); \
     return true;                            \
   }
   MPDATA_WM_LPS(X)
@@ -127,7 +129,7 @@ bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream) {
 }
 // fp32 plans: two adjacent instances per lane (8-byte elements = pairs of fp32 values, packed
 // arithmetic); `a` describes the arrays in PAIRS (ncrms / 2 of them)
-bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stream) {
+bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stream, int flags) {
   if (wpb != 4) return false;
   MpdataWmArgsT<v2::f32x2> a;
   a.f = reinterpret_cast<v2::f32x2*>(a8.f);
@@ -139,7 +141,7 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   a.tile_elems = a8.tile_elems; a.f_tstride = a8.f_tstride; a.flux_tstride = a8.flux_tstride; a.reverse = a8.reverse;
 #define X(LPS_)                                \
   if (lps == LPS_) {                           \
-    launch_wm_t<v2::f32x2, LPS_, 4>(a, stream); \
+    launch_wm_t<v2::f32x2, LPS_, 4>(a, stream, flags); \
     return true;                               \
   }
   MPDATA_WM_LPS(X)
@@ -148,6 +150,46 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
 }
 
 int max_tile_id() { return 43; }
+
+// Experiment / timing-ablation macros this translation unit was compiled with (some of them
+// produce wrong results by design).  Empty for a production build; part of mpdata_version().
+const char* build_flags() {
+  return ""
+#ifdef MPDWM_ABL_NODMA
+         " MPDWM_ABL_NODMA"
+#endif
+#ifdef MPDWM_ABL_NOCOMPUTE
+         " MPDWM_ABL_NOCOMPUTE"
+#endif
+#ifdef MPDWM_ABL_FIRSTPASS
+         " MPDWM_ABL_FIRSTPASS"
+#endif
+#ifdef MPD2_ABL_NOMEM
+         " MPD2_ABL_NOMEM"
+#endif
+#ifdef MPD2_ABL_NODMA
+         " MPD2_ABL_NODMA"
+#endif
+#ifdef MPD2_ABL_NOCOMPUTE
+         " MPD2_ABL_NOCOMPUTE"
+#endif
+#ifdef MPD2_STAMPS
+         " MPD2_STAMPS"
+#endif
+#ifdef MPD2_NO_XCD_TRACERS
+         " MPD2_NO_XCD_TRACERS"
+#endif
+#ifdef MPD_DPP_NOP1
+         " MPD_DPP_NOP1"
+#endif
+#if MPD2_ST_AUX != 0
+         " MPD2_ST_AUX"
+#endif
+#if MPD2_LD_AUX != 0
+         " MPD2_LD_AUX"
+#endif
+      ;
+}
 
 bool tile_info(int id, MpdataTileInfo* info) {
 #define X(ID, W_, SPW_, NWV_)                                                     \

@@ -107,6 +107,15 @@ int mpdata_plan_upload(mpdata_plan* plan, const double* f, const double* u, cons
                        const double* flux);              /* host arrays; flux may be NULL */
 int mpdata_plan_run(mpdata_plan* plan);            /* all tracers; async on the plan's stream */
 int mpdata_plan_run_tracers(mpdata_plan* plan, int first_tracer, int ntracers); /* a sub-range */
+/* One step on FRESH velocities: u, w are reference-layout DEVICE arrays of the plan's precision
+ * (what a CRM whose state lives on the device produces every step; the reference's timed region
+ * takes whatever u, w the device arrays hold, :107-110), f, rho, rhow, adz stay in the plan.
+ * Entering the plan layout is part of the call and of its event time.  One fp64 tracer of a
+ * wave-major plan: a kernel that reads u, w straight from the reference layout (128-byte row
+ * segments through an LDS ring shared by the 8 waves of a workgroup) while f streams in the
+ * plan layout -- no conversion pass; tracer batches: one fused u+w conversion, then the batch
+ * kernel (the plan's u, w are then the new ones). */
+int mpdata_plan_run_uw(mpdata_plan* plan, int first_tracer, int ntracers, const void* u, const void* w);
 int mpdata_plan_sync(mpdata_plan* plan);           /* the `!$acc wait` (:237) */
 int mpdata_plan_download(mpdata_plan* plan, double* f, double* flux);  /* host arrays */
 int mpdata_plan_last_kernel_ms(mpdata_plan* plan, double* ms); /* hipEvent time of the last run */
@@ -217,6 +226,16 @@ int mpdata_debug_stages_device(int64_t ncrms, int nx, int nz, int last_stage, do
 /* ---- 8. Misc. */
 int mpdata_set_variant(int variant);      /* MPDATA_VARIANT_*; returns previous */
 int mpdata_get_variant(void);
+/* Serpentine tile order of wave-major plans (every other run of a plan walks its tiles from the
+ * other end and so starts on what the previous run left in the Infinity Cache; +2 % when
+ * consecutive runs share u, w).  OFF by default (MPDATA_SERPENTINE=1 in the environment turns it
+ * on); returns the previous setting. */
+int mpdata_set_serpentine(int on);
+/* Test switches of the wave-major launch (bit 0: the batch form of the kernel for one tracer as
+ * well, bit 1: one tracer per wave in tracer batches, bit 2: an odd last tracer stays in the
+ * two-tracer launch; MPDATA_WM_NOSTREAM / MPDATA_WM_TPW1 / MPDATA_WM_NOSPLIT in the environment
+ * set the initial value); flags < 0 only queries.  Returns the previous value. */
+int mpdata_set_wm_flags(int flags);
 int mpdata_set_tile(int tile);            /* kernel tiling id; -1 = default */
 int mpdata_set_debug_buffer(void* dev_ptr); /* diagnostic builds only: clock-stamp buffer */
 int mpdata_device_count(void);

@@ -35,6 +35,14 @@ def M(mpdata):
     mpdata.set_plan_layout(mpdata.LAYOUT_WAVEMAJOR)
 
 
+@pytest.fixture(autouse=True)
+def _default_launch_switches(mpdata):
+    """every test starts from, and leaves behind, the default wave-major launch (no test switch set)"""
+    mpdata.set_wm_flags(0)
+    yield
+    mpdata.set_wm_flags(0)
+
+
 def run_plan_host(M, inp, ntr=1):
     """upload -> run -> download on host arrays; returns (f, flux)."""
     ncrms, nxp6, nzm = inp["f"].shape[:3]
@@ -102,8 +110,9 @@ def test_wavemajor_plan_shapes(M, oracle, shape, variant, dist):
 def test_batch_form_of_the_kernel_on_single_tracers(M, oracle, monkeypatch, shape, variant):
     """The kernel has two forms (mpdata_kernel_wm_body.h): streaming fetch / store for one tracer per
     launch, default cache policy with one instruction per array for tracer batches.
-    MPDATA_WM_NOSTREAM runs the batch form on single-tracer problems, so that it sees all the shapes."""
-    monkeypatch.setenv("MPDATA_WM_NOSTREAM", "1")
+    The NOSTREAM launch switch (mpdata_set_wm_flags) runs the batch form on single-tracer problems, so
+    that it sees all the shapes."""
+    M.set_wm_flags(M.WMF_NOSTREAM)
     var = M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST
     M.set_variant(var)
     inp = oracle.make_inputs(*shape, seed=13, dist=3)
@@ -119,13 +128,13 @@ def test_batch_form_of_the_kernel_on_single_tracers(M, oracle, monkeypatch, shap
 def test_tracer_batches_two_tracers_per_wave(M, oracle, monkeypatch, shape, ntr, mode):
     """Tracer batches run TWO tracers per wave (u, w and the tracer-independent factors formed once
     for both); the last tracer of an odd count goes through the one-tracer kernel, or -- with
-    MPDATA_WM_NOSPLIT -- stays in the batch launch paired with an empty buffer range.  Every tracer
+    the NOSPLIT launch switch -- stays in the batch launch paired with an empty buffer range.  Every tracer
     must equal a single-tracer call of the oracle, on all lane mappings (nz <= 8 / 16 / 32 / 64) and
-    ragged tile counts.  MPDATA_WM_TPW1 keeps the one-tracer-per-wave batch kernel covered."""
+    ragged tile counts.  The TPW1 switch keeps the one-tracer-per-wave batch kernel covered."""
     if mode.endswith("per-wave"):
-        monkeypatch.setenv("MPDATA_WM_TPW1", "1")
+        M.set_wm_flags(M.WMF_TPW1)
     if mode.endswith("in-the-batch"):
-        monkeypatch.setenv("MPDATA_WM_NOSPLIT", "1")
+        M.set_wm_flags(M.WMF_NOSPLIT)
     var = M.VARIANT_FAST if mode == "fast" else M.VARIANT_EXACT
     M.set_variant(var)
     ncrms, nx, nz = shape
@@ -280,10 +289,7 @@ def test_random_shapes_both_forms(M, oracle, monkeypatch):
         ncrms = int(rng.integers(1, 301))
         nx = int(rng.integers(1, 71))
         nz = int(rng.choice([rng.integers(3, 9), rng.integers(9, 17), rng.integers(17, 33), rng.integers(33, 65)]))
-        if it % 2:
-            monkeypatch.setenv("MPDATA_WM_NOSTREAM", "1")
-        else:
-            monkeypatch.delenv("MPDATA_WM_NOSTREAM", raising=False)
+        M.set_wm_flags(M.WMF_NOSTREAM if it % 2 else 0)
         inp = oracle.make_inputs(ncrms, nx, nz, seed=1000 + it, dist=3 if it % 3 else 1)
         f, flux = run_plan_host(M, inp)
         f_ref, flux_ref = oracle.advect(inp, nthreads=4)
