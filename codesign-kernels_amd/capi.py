@@ -94,6 +94,8 @@ def lib():
         L.mpdata_shard_range.argtypes = [i64, ci, ci, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         L.mpdata_plan_ngpus.restype = ci
         L.mpdata_plan_ngpus.argtypes = [vp]
+        L.mpdata_plan_ranks_seen.restype = ci
+        L.mpdata_plan_ranks_seen.argtypes = [vp]
         L.mpdata_plan_shard.restype = ci
         L.mpdata_plan_shard.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(i64), ctypes.POINTER(i64)]
         L.mpdata_plan_shard_plan.restype = vp
@@ -390,6 +392,11 @@ class Plan:
     @property
     def ngpus(self):
         return lib().mpdata_plan_ngpus(self._p)
+
+    @property
+    def ranks_seen(self):
+        """ranks the plan's RCCL communicator reports (ncclCommCount); 0 if the plan has none"""
+        return lib().mpdata_plan_ranks_seen(self._p)
 
     def shards(self):
         """[(device, sl0, nloc)] of the plan's GPUs."""

@@ -42,6 +42,10 @@ struct MpdataWmArgsT {
   long long f_tstride;     // elements between consecutive tracers of f: ntiles * tile_elems
   long long flux_tstride;  // ... of flux: ntiles * SLP * nzm
   int reverse;             // walk the tiles from the last to the first
+  // mpdata_plan_run_uw (kernel instantiation UWREF): u, w in the REFERENCE layout instead of a.u, a.w
+  const R* u_ref;          // u(ncrms, nx+5, nzm)
+  const R* w_ref;          // w(ncrms, nx+4, nz)
+  long long ncrms;         // leading dimension of u_ref, w_ref
 };
 typedef MpdataWmArgsT<double> MpdataWmArgs;
 // test switches of the wave-major launch (mpdata_set_wm_flags; MPDATA_WM_NOSTREAM / _TPW1 / _NOSPLIT)

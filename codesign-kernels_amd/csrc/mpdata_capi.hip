@@ -311,8 +311,10 @@ int mpdata_advect_scalar2d_f32_device(int64_t ncrms, int nx, int nz, int ntracer
 namespace mpdata_exact {
 bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
 bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
+bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream);
 }
 namespace mpdata_fast {
+bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream);
 bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
 bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
 }
@@ -442,6 +444,12 @@ int plan_stage(mpdata_plan* p) {
   return 0;
 }
 
+// MPDATA_LAYOUT_LEGACY=1: the round-2 conversion kernel (one workgroup per column) for f, u, w as well (A/B)
+bool legacy_convert() {
+  static const bool v = getenv("MPDATA_LAYOUT_LEGACY") != nullptr;
+  return v;
+}
+
 // Arrays in the reference layout -> the plan.  `dev` says where the pointers live.  Null
 // pointers are skipped (the plan keeps what it has).  f / flux cover `count` tracers.
 int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, const void* rho,
@@ -465,25 +473,36 @@ int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, con
     const int rs = plan_stage(p);
     if (rs) return rs;
   }
+  // f, u, w (many columns, split chunks): the column-walking kernel; the small arrays: the per-column one
+  auto conv = [&](int which, void* ref, int tr, int ntr) -> int {
+    const MpdataLayoutJob j = wm_job(p, which, ref, tr, ntr);
+    if (which <= 2 && !legacy_convert()) HIP_TRY(mpdata_layout_convert_cols(&j, 1, true, p->stream));
+    else HIP_TRY(mpdata_layout_convert(j, 8, true, p->stream));
+    return 0;
+  };
   auto one = [&](int which, const void* src, size_t elems, int tr) -> int {
     void* ref = const_cast<void*>(src);
     if (!dev) {
       HIP_TRY(hipMemcpyAsync(p->stage, src, elems * eb, hipMemcpyHostToDevice, p->stream));
       ref = p->stage;
     }
-    HIP_TRY(mpdata_layout_convert(wm_job(p, which, ref, tr, 1), 8, true, p->stream));
-    return 0;
+    return conv(which, ref, tr, 1);
   };
   int rc = 0;
   if (f) {
     if (dev) {
-      HIP_TRY(mpdata_layout_convert(wm_job(p, 0, const_cast<void*>(f), first, count), 8, true, p->stream));
+      rc = conv(0, const_cast<void*>(f), first, count);
     } else {
       for (int t = 0; t < count && !rc; ++t) rc = one(0, (const char*)f + (size_t)t * f1 * eb, f1, first + t);
     }
   }
-  if (!rc && u) rc = one(1, u, p->sz.u, 0);
-  if (!rc && w) rc = one(2, w, p->sz.w, 0);
+  if (!rc && u && w && dev && !legacy_convert()) {   // u and w of a device import: ONE launch
+    const MpdataLayoutJob j2[2] = {wm_job(p, 1, const_cast<void*>(u), 0, 1), wm_job(p, 2, const_cast<void*>(w), 0, 1)};
+    HIP_TRY(mpdata_layout_convert_cols(j2, 2, true, p->stream));
+  } else {
+    if (!rc && u) rc = one(1, u, p->sz.u, 0);
+    if (!rc && w) rc = one(2, w, p->sz.w, 0);
+  }
   if (!rc && rho) rc = one(3, rho, p->sz.k, 0);
   if (!rc && rhow) rc = one(4, rhow, p->sz.kz, 0);
   if (!rc && adz) rc = one(5, adz, p->sz.k, 0);
@@ -506,14 +525,22 @@ int plan_export(mpdata_plan* p, void* f, void* flux, int first, int count, bool 
     if (flux) HIP_TRY(hipMemcpyAsync(flux, (char*)p->flux + first * p->sz.kz * eb, p->sz.kz * count * eb, kind, p->stream));
     return 0;
   }
+  auto conv_out = [&](void* ref, int tr, int ntr) -> int {
+    const MpdataLayoutJob j = wm_job(p, 0, ref, tr, ntr);
+    if (!legacy_convert()) HIP_TRY(mpdata_layout_convert_cols(&j, 1, false, p->stream));
+    else HIP_TRY(mpdata_layout_convert(j, 8, false, p->stream));
+    return 0;
+  };
   if (f) {
     if (dev) {
-      HIP_TRY(mpdata_layout_convert(wm_job(p, 0, f, first, count), 8, false, p->stream));
+      const int rc = conv_out(f, first, count);
+      if (rc) return rc;
     } else {
       const int rs = plan_stage(p);
       if (rs) return rs;
       for (int t = 0; t < count; ++t) {
-        HIP_TRY(mpdata_layout_convert(wm_job(p, 0, p->stage, first + t, 1), 8, false, p->stream));
+        const int rc = conv_out(p->stage, first + t, 1);
+        if (rc) return rc;
         HIP_TRY(hipMemcpyAsync((char*)f + (size_t)t * f1 * eb, p->stage, f1 * eb, hipMemcpyDeviceToHost, p->stream));
       }
     }
@@ -651,9 +678,16 @@ int mpdata_plan_import_device(mpdata_plan* p, const void* f, const void* u, cons
                               const void* rhow, const void* adz, const void* flux, int first_tracer,
                               int ntracers) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
-  if (p->multi) return set_err(MPDATA_EUNSUPPORTED, "device import into a multi-GPU plan: use mpdata_plan_shard_plan()");
   int rc = tracer_range(p, first_tracer, ntracers);
   if (rc) return rc;
+  if (p->multi) {   // the arrays live on the ROOT GPU (shard 0's device), full width: scatter them (RCCL over xGMI)
+    rc = mpdata_multi_scatter_device(p->multi, f, u, w, rho, rhow, adz, flux, first_tracer, ntracers);
+    if (!rc) {
+      p->uploaded = true;
+      for (int g = 0; g < mpdata_multi_ngpus(p->multi); ++g) mpdata_multi_sub(p->multi, g)->uploaded = true;
+    }
+    return rc;
+  }
   DevGuard g(p->device);
   rc = plan_import(p, f, u, w, rho, rhow, adz, flux, first_tracer, ntracers, true);
   if (rc) return rc;
@@ -663,16 +697,21 @@ int mpdata_plan_import_device(mpdata_plan* p, const void* f, const void* u, cons
 
 int mpdata_plan_export_device(mpdata_plan* p, void* f, void* flux, int first_tracer, int ntracers) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
-  if (p->multi) return set_err(MPDATA_EUNSUPPORTED, "device export from a multi-GPU plan: use mpdata_plan_shard_plan()");
   int rc = tracer_range(p, first_tracer, ntracers);
   if (rc) return rc;
+  if (p->multi) {   // gather to arrays on the root GPU
+    for (int g = 0; g < mpdata_multi_ngpus(p->multi); ++g)
+      if (!mpdata_multi_sub(p->multi, g)->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_export_device before upload / import (shard %d)", g);
+    return mpdata_multi_gather_device(p->multi, f, flux, first_tracer, ntracers);
+  }
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_export_device before upload / import");
   DevGuard g(p->device);
   return plan_export(p, f, flux, first_tracer, ntracers, true);
 }
 
 // the kernel launch(es) of one run of a single-device plan, on the plan's stream
-static int plan_launch(mpdata_plan* p, int first, int count) {
+// (u_ref, w_ref != null: the kernel that reads u, w from these reference-layout arrays)
+static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref = nullptr, const void* w_ref = nullptr) {
   int rc = 0;
   if (p->layout == MPDATA_LAYOUT_WAVEMAJOR) {
     MpdataWmArgs a;
@@ -684,7 +723,15 @@ static int plan_launch(mpdata_plan* p, int first, int count) {
     a.f_tstride = (long long)p->ntiles * p->tile_elems;
     a.flux_tstride = (long long)p->ntiles * p->chunk;
     a.reverse = serpentine() ? (int)(p->runs++ & 1u) : 0;
+    a.u_ref = (const double*)u_ref; a.w_ref = (const double*)w_ref; a.ncrms = p->ncrms;
     const bool fast = p->variant == MPDATA_VARIANT_FAST;
+    if (u_ref) {
+      a.reverse = 0;
+      const bool okx = fast ? mpdata_fast::launch_wm_uw(p->lps, a, (void*)p->stream) : mpdata_exact::launch_wm_uw(p->lps, a, (void*)p->stream);
+      if (!okx) return set_err(MPDATA_EINVAL, "wave-major u,w-reference kernel LPS=%d not instantiated", p->lps);
+      HIP_TRY(hipGetLastError());
+      return 0;
+    }
     const int fl = wm_flags();
     const bool ok = p->eb == 8 ? (fast ? mpdata_fast::launch_wm(p->lps, p->wpb, a, (void*)p->stream, fl)
                                        : mpdata_exact::launch_wm(p->lps, p->wpb, a, (void*)p->stream, fl))
@@ -742,9 +789,20 @@ int mpdata_plan_run_uw(mpdata_plan* p, int first, int count, const void* u, cons
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run_uw before upload / import");
   DevGuard g(p->device);
   HIP_TRY(hipEventRecord(p->ev0, p->stream));
-  rc = plan_import(p, nullptr, u, w, nullptr, nullptr, nullptr, nullptr, 0, 1, true);
-  if (rc) return rc;
-  rc = plan_launch(p, first, count);
+  // one fp64 tracer of a wave-major plan: the kernel fetches u, w from the caller's arrays itself
+  // (16-byte row pieces: even ncrms, 16-byte aligned bases; 32-bit offsets: arrays below 4 GiB);
+  // MPDATA_RUN_UW=import forces the conversion path (tests, A/B)
+  static const bool force_import = getenv("MPDATA_RUN_UW") && !strcmp(getenv("MPDATA_RUN_UW"), "import");
+  const bool direct = p->layout == MPDATA_LAYOUT_WAVEMAJOR && p->eb == 8 && count == 1 && (p->ncrms & 1) == 0 && p->lps <= 32 &&
+                      (((uintptr_t)u | (uintptr_t)w) & 15) == 0 &&
+                      (double)p->ncrms * (p->nx + 5) * p->nz * 8.0 < 4294967000.0 && !force_import;
+  if (direct) {
+    rc = plan_launch(p, first, count, u, w);
+  } else {
+    rc = plan_import(p, nullptr, u, w, nullptr, nullptr, nullptr, nullptr, 0, 1, true);
+    if (rc) return rc;
+    rc = plan_launch(p, first, count);
+  }
   if (rc) return rc;
   HIP_TRY(hipEventRecord(p->ev1, p->stream));
   p->ran = true;
@@ -842,6 +900,10 @@ int mpdata_plan_create_multi(int64_t ncrms, int nx, int nz, int ntracers, int ng
 int mpdata_plan_create_multi_devices(int64_t ncrms, int nx, int nz, int ntracers, int ngpus, const int* devices,
                                      mpdata_plan** plan) {
   return plan_create_multi(ncrms, nx, nz, ntracers, ngpus, devices, plan, 8);
+}
+int mpdata_plan_ranks_seen(const mpdata_plan* p) {
+  if (!p) return MPDATA_EINVAL;
+  return p->multi ? mpdata_multi_ranks_seen(p->multi) : 0;
 }
 int mpdata_plan_ngpus(const mpdata_plan* p) { return !p ? MPDATA_EINVAL : (p->multi ? mpdata_multi_ngpus(p->multi) : 1); }
 int mpdata_plan_shard(const mpdata_plan* p, int g, int* device, int64_t* sl0, int64_t* nloc) {

@@ -49,6 +49,16 @@
 
 #include "mpdata_args.h"
 
+// experiments on the kernel that reads u, w from the reference layout (UWREF): where in a pair the
+// workgroup's u, w fetch is issued (0: behind the barrier, 1: between the pair's two steps, 2: behind
+// the second), cache policy of those fetches (2 = streaming)
+#ifndef MPDWX_UW_POS
+#define MPDWX_UW_POS 1
+#endif
+#ifndef MPDWX_UW_AUX
+#define MPDWX_UW_AUX 2
+#endif
+
 namespace MPDATA_NS {
 namespace wm {
 
@@ -126,9 +136,19 @@ template <typename R> __device__ __forceinline__ R second(R x) { return x; }
 template <typename R> __device__ __forceinline__ R first(Pair<R> x) { return x.a; }
 template <typename R> __device__ __forceinline__ R second(Pair<R> x) { return x.b; }
 
-template <typename R_, int LPS, int WPB_, int TPW_ = 1>
+// UWREF_ (mpdata_plan_run_uw): u and w are NOT in the plan layout but in the caller's reference layout
+// (sl fastest).  A workgroup is then the 16/SLP waves whose tiles are 16 ADJACENT instances: the
+// 128-byte row segments (16 instances of one (column, level)) of u and w arrive by 16-byte LDS-DMA in
+// a ring of column pairs that the whole workgroup shares -- one barrier per column PAIR --, f still
+// streams per wave in the plan layout.
+template <typename R_, int LPS, int WPB_, int TPW_ = 1, bool UWREF_ = false>
 struct TileWm {
   using R = R_;
+  static constexpr bool XU = UWREF_;
+  static constexpr int GX = 16;                 // UWREF: instances per workgroup (128-byte rows)
+  static constexpr int XRG = LPS / 8;           // UWREF: groups of 8 rows (one DMA instruction) per array block
+  static constexpr int XARR = LPS * GX;         // UWREF: elements of one (column, array) block: LPS rows x 16
+  static constexpr int XSLOT = 4 * XARR;        // UWREF: a pair slot of the shared ring: [column of pair][u, w]
   static constexpr int SLP = 64 / LPS;          // instances per wave = per tile
   static constexpr int WPB = WPB_;              // waves (= tiles) per workgroup; they never synchronise
   static constexpr int THREADS = 64 * WPB_;
@@ -138,11 +158,20 @@ struct TileWm {
   static constexpr int ARR = 128;               // elements of one array block of a slot (1 KiB)
   static constexpr int TPW = TPW_;              // tracers per wave (tracer batches: 1 or 2)
   static constexpr int UO = TPW_ * ARR, WO = (TPW_ + 1) * ARR;   // a slot: f of every tracer of the wave, u, w
-  static constexpr int SLOT = (2 + TPW_) * ARR;
-  static constexpr int LDS_ELEMS = WPB_ * NS * SLOT;
+  static constexpr int SLOT = UWREF_ ? ARR : (2 + TPW_) * ARR;   // (UWREF: the wave's own ring holds f only)
+  static constexpr int LDS_ELEMS = WPB_ * NS * SLOT + (UWREF_ ? NS * XSLOT : 0);
+  static_assert(!UWREF_ || (WPB_ * (64 / LPS) == GX && TPW_ == 1), "UWREF: 16 instances per workgroup, one tracer per wave");
   // 128 VGPRs; one instance per wave (LPS = 64) carries the ghost-level select of w and gets 168
   // (two tracers per wave: twice the tracer state, 256 VGPRs, 2 waves per SIMD)
-  static constexpr int MIN_WAVES = TPW_ == 2 ? 2 : (LPS == 64 ? 3 : 4);
+  // UWREF: 16 / SLP waves per workgroup.  FAST fits 128 VGPRs (two workgroups of 8 waves per CU at
+  // LPS = 32); EXACT (the IEEE divisions, no folded constants) does not: it gets 256 and runs one
+  // workgroup per CU -- it is the parity variant of this kernel, not the fast one.
+#ifdef MPDATA_FAST_DIV
+  static constexpr int MIN_WAVES_X = 4;
+#else
+  static constexpr int MIN_WAVES_X = 2;
+#endif
+  static constexpr int MIN_WAVES = UWREF_ ? MIN_WAVES_X : (TPW_ == 2 ? 2 : (LPS == 64 ? 3 : 4));
   static_assert(sizeof(R_) == 8, "8-byte elements (double, or two fp32 instances per lane)");
 };
 
@@ -155,11 +184,12 @@ struct TileWm {
 // upwind selects, the u / w sums and the tracer-independent factors of the antidiffusive fluxes
 // (:571-573, :580-582) are fetched / formed once for both, the tracer state (register pipeline,
 // flux sums, store) is a Pair.
-template <typename R, int LPS, int WPB, bool STREAM, int TPW = 1>
-__global__ void __launch_bounds__(64 * WPB, (TileWm<R, LPS, WPB, TPW>::MIN_WAVES))
+template <typename R, int LPS, int WPB, bool STREAM, int TPW = 1, bool UWREF = false>
+__global__ void __launch_bounds__(64 * WPB, (TileWm<R, LPS, WPB, TPW, UWREF>::MIN_WAVES))
 mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
-  using T = TileWm<R, LPS, WPB, TPW>;
+  using T = TileWm<R, LPS, WPB, TPW, UWREF>;
   static_assert(TPW == 1 || (TPW == 2 && !STREAM), "two tracers per wave: batch form only");
+  static_assert(!UWREF || (STREAM && TPW == 1), "u, w from the reference layout: one tracer per launch");
   using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
   constexpr int SLP = T::SLP, RB = (int)sizeof(R);
   __shared__ R lds[T::LDS_ELEMS];
@@ -184,10 +214,19 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     tr = (v % ntw) * TPW;                                 // first tracer of the wave
     tile = (v / ntw) * nxcd + blockIdx.x % nxcd;
   }
-  if (tile >= (unsigned)a.ntiles) return;  // (no barrier anywhere below)
-  // serpentine: every other run of a plan walks the tiles from the other end, so that it starts
-  // on what the previous run touched last (u, w and the like are still in the Infinity Cache)
-  if (a.reverse) tile = (unsigned)a.ntiles - 1u - tile;
+  // UWREF: the waves of a workgroup share the u, w ring (barriers, a share of the row fetches each):
+  // a wave beyond the last tile stays, works on an EMPTY f range (fetches deliver zeros, stores are
+  // dropped) and reads the constants of the last tile
+  bool tile_ok = true;
+  if constexpr (UWREF) {
+    tile_ok = tile < (unsigned)a.ntiles;
+    if (!tile_ok) tile = (unsigned)a.ntiles - 1u;
+  } else {
+    if (tile >= (unsigned)a.ntiles) return;  // (no barrier anywhere below)
+    // serpentine: every other run of a plan walks the tiles from the other end, so that it starts
+    // on what the previous run touched last (u, w and the like are still in the Infinity Cache)
+    if (a.reverse) tile = (unsigned)a.ntiles - 1u - tile;
+  }
 
   const int chunk = SLP * nzm;                    // elements of one column of the tile
   const unsigned chunkB = (unsigned)(chunk * RB);
@@ -243,13 +282,55 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   const unsigned mainB = chunkB / 128u * 128u, remB = chunkB - mainB;
   const unsigned remBase = (unsigned)ncol * mainB;
   const long long tileB = (long long)ncol * chunkB;
-  const __amdgpu_buffer_rsrc_t rsf = v2::make_rsrc(f, tileB);
+  const __amdgpu_buffer_rsrc_t rsf = v2::make_rsrc(f, (UWREF && !tile_ok) ? 0 : tileB);
   const __amdgpu_buffer_rsrc_t rsf1 = v2::make_rsrc(f1, has1 ? tileB : 0);
-  const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, tileB);
-  const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, tileB);
+  const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, UWREF ? 0 : tileB);   // (UWREF: not used)
+  const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, UWREF ? 0 : tileB);
+  // ---- UWREF: u, w in the reference layout (sl fastest, :33-38): u(ncrms, nx+5, nzm), w(ncrms, nx+4, nz).
+  //      Row (column c, level kk) of the workgroup = 16 instances = 128 bytes at
+  //        ((c-1) + ncols*kk) * ncrms*8 + sl_base*8          (u, w have no column c = 0).
+  //      One 16-byte-per-lane LDS-DMA instruction fetches 8 rows (8 lanes each); wave wv fetches row
+  //      group wv % XRG of array wv / XRG (u: 0, w: 1), the two columns of a pair with one instruction
+  //      each -- same per-lane offset, the column is the scalar offset.  LDS image of a block:
+  //      [row][16 instances], the 16-byte chunk (2 instances) at position p of row r holds source
+  //      chunk p ^ ((r >> 1) & 7) (swizzle on the SOURCE address): a wave's transposed read (lanes
+  //      along the rows, 8 bytes of one chunk each) is then 2-way bank-conflicted at worst.
+  R* const xring = lds + WPB * (T::NS * T::SLOT);
+  [[maybe_unused]] unsigned xv = 0xFFFFFFF8u, x_colB = 0;
+  [[maybe_unused]] int x_ncols = 0, x_dst = 0;
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsx = rsu;
+  [[maybe_unused]] const R *x_own = lds, *x_dn = lds, *x_up = lds;
+  if constexpr (UWREF) {
+    const int xa = wave / T::XRG, xrg = wave % T::XRG;          // this wave's array and row group
+    x_ncols = xa == 0 ? nx + 5 : nx + 4;                         // columns of the array
+    const long long lvl = a.ncrms * (long long)x_ncols;          // elements between levels
+    const long long rows_a = xa == 0 ? nzm : nz;                 // levels the array holds
+    rsx = v2::make_rsrc(xa == 0 ? a.u_ref : a.w_ref, lvl * rows_a * RB);
+    x_colB = (unsigned)(a.ncrms * RB);
+    const int rl = lane >> 3, row = xrg * 8 + rl;                // the lane's row of the block
+    const int pch = lane & 7;                                     // its 16-byte chunk position in the LDS row
+    const long long sl_src = (long long)blockIdx.x * T::GX + 2 * (pch ^ ((row >> 1) & 7));
+    // rows >= nzm (w: level nz is never read, :511) and instances beyond the array's end fetch nothing:
+    // out of range = zeros into that part of the block
+    const bool ok = row < nzm && sl_src + 1 < a.ncrms;
+    xv = ok ? (unsigned)((sl_src + lvl * row) * RB) : 0xFFFFFFF8u;
+    x_dst = xa * T::XARR + xrg * 8 * T::GX;                      // element offset inside a [column] half slot
+    // read positions: row = level index (ghost and dead lanes: the zero rows nzm .. LPS-1)
+    const int s_g = wave * SLP + lane / LPS;                     // instance inside the workgroup
+    auto xpos = [&](const int r) __attribute__((always_inline)) {
+      return r * T::GX + ((((s_g >> 1) ^ ((r >> 1) & 7)) << 1) | (s_g & 1));
+    };
+    const int kk_ = lane % LPS;
+    const bool real = kk_ < nzm;
+    x_own = xring + xpos(kk_);
+    x_dn = xring + xpos(kk_ > 0 ? kk_ - 1 : 0);
+    x_up = xring + xpos(real ? (kk_ + 1 < nzm ? kk_ + 1 : nzm - 1) : (kk_ + 1 < LPS ? kk_ + 1 : LPS - 1));
+  }
   const unsigned posB = (unsigned)(pos * RB);
   const unsigned st_main = (lvl_ok && posB < mainB) ? posB : OOB;               // the lane's element of a chunk:
   const unsigned st_rem = (lvl_ok && posB >= mainB) ? remBase + (posB - mainB) : OOB;  // in one of the two parts
+  [[maybe_unused]] const bool st_in_main = posB < mainB;
+  [[maybe_unused]] const unsigned st_ab = lvl_ok ? (st_in_main ? posB : remBase + (posB - mainB)) : OOB;
   // DMA source offsets of a pair instruction: lane L < 32 fetches bytes 16L.. of the even column,
   // lane L >= 32 bytes 16(L-32).. of the odd one (the LDS image keeps the two columns 512 B apart);
   // the lanes of a column's main part in the one instruction, those of its remainder in the other
@@ -303,7 +384,12 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     return;
 #endif
     R* d = my + (P % T::NS) * T::SLOT;
-    if constexpr (STREAM) {
+    if constexpr (UWREF) {   // f only (u, w: dma_uw); ONE offset register for both parts (dcur: never advanced here)
+      const unsigned soA = (unsigned)(2 * P) * mainB, soB = (unsigned)(2 * P) * remB;
+      const unsigned of_ = halves(dcur, ef, of);
+      if (lane_main) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)of_, (int)soA, 0, AUX_NT);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(d), 16, (int)of_, (int)soB, 0, 0);
+    } else if constexpr (STREAM) {
       const unsigned soA = (unsigned)(2 * P) * mainB, soB = (unsigned)(2 * P) * remB;
       // A lane that is out of range in an LDS-DMA instruction still writes (zeros) to its LDS
       // position, so the two instructions of an array must not both be executed by a lane: the
@@ -330,6 +416,17 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     const int c0 = 2 * P, c1 = 2 * P + 1;  // the pair's columns
     dma_issue(P, c0 < ncol, c1 < ncol, c0 >= 1 && c0 < ncol, c1 < ncol, c0 >= 1 && c0 <= nx + 4, c1 <= nx + 4);
   };
+  // UWREF: this wave's share of u / w of pair P into the workgroup's ring (two instructions: the
+  // pair's two columns).  A column that does not exist for the array fetches nothing (zeros).
+  [[maybe_unused]] auto dma_uw = [&](const int P) __attribute__((always_inline)) {
+    if constexpr (UWREF) {
+      R* d = xring + (P % T::NS) * T::XSLOT + x_dst;
+      const int c0 = 2 * P, c1 = 2 * P + 1;
+      const bool e0 = c0 >= 1 && c0 <= x_ncols, e1 = c1 <= x_ncols;   // u: c = 1 .. nx+5, w: c = 1 .. nx+4
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(d), 16, (int)(e0 ? xv : OOB), (int)((unsigned)max(c0 - 1, 0) * x_colB), 0, MPDWX_UW_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(d + 2 * T::XARR), 16, (int)(e1 ? xv : OOB), (int)((unsigned)max(c1 - 1, 0) * x_colB), 0, MPDWX_UW_AUX);
+    }
+  };
   // interior pairs (1 <= P, 2P+1 <= nx+4): no conditions
   auto dma_pair_full = [&](const int P) __attribute__((always_inline)) {
     dma_issue(P, true, true, true, true, true, true);
@@ -344,7 +441,11 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     if (__builtin_bit_cast(double, first(v)) != 1.2345e300) return;
 #endif
     const v2::u32x2 b = __builtin_bit_cast(v2::u32x2, first(v));
-    if constexpr (STREAM) {
+    if constexpr (UWREF) {   // as STREAM, with ONE offset register: a lane's element lies in one of the two parts
+      const unsigned o = act ? st_ab : OOB;
+      if (st_in_main) __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)o, (int)((unsigned)c * mainB), AUX_NT);
+      else __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)o, (int)((unsigned)c * remB), 0);
+    } else if constexpr (STREAM) {
       __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)(act ? st_main : OOB), (int)((unsigned)c * mainB), AUX_NT);
       __builtin_amdgcn_raw_buffer_store_b64(b, rsf, (int)(act ? st_rem : OOB), (int)((unsigned)c * remB), 0);
     } else {
@@ -374,6 +475,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     st_col(false, 0, V(R(0)), std::integral_constant<int, 1>{});
     st_col(false, 0, V(R(0)), std::integral_constant<int, 1>{});
     dma_pair(P);
+    if (UWREF && P < 2) dma_uw(P);   // issue order f(0) uw(0) f(1) uw(1) f(2): what the counted wait assumes
   }
   __builtin_amdgcn_sched_barrier(0);
   const R IRHO = recip_const(RHO);
@@ -440,7 +542,13 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 
     V f0q;
     R uq, wq;   // (ghost level: w = 0)
-    if constexpr (TPW == 1) {
+    // UWREF: u, w of the column from the workgroup's ring ([pair slot][column of pair][u, w] blocks)
+    constexpr int XO = decltype(sl_tag)::value * T::XSLOT + decltype(h_tag)::value * 2 * T::XARR;
+    if constexpr (UWREF) {
+      f0q = ldv(p_own + LO);
+      uq = x_own[XO];
+      wq = x_own[XO + T::XARR];   // (ghost level: a zero row)
+    } else if constexpr (TPW == 1) {
       f0q = ldv(p_own + LO);
       uq = p_own[LO + T::UO];
       wq = p_own[LO + T::WO];
@@ -472,7 +580,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
       if (FULL || q <= nx + 2) {
         const V W1q = upwind(wq, f0d, f0q);  // :537
         DW1q = UP_G(W1q) - W1q;
-        if (FULL || (q >= 1 && q <= nx)) S1 = S1 + W1q;  // :545
+        if (FULL || (q >= 1 && q <= nx)) S1 = S1 + W1q;  // :545 (UWREF: S1 also takes the limited terms)
       }
       if (FULL || q >= 0) {
         f1_1 = F0p - ((U1q - S.U1[C1]) + S.DW1[C1] * IADZ) * IRHO;  // :557, column q-1
@@ -499,7 +607,10 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 
     // u / w sums for the antidiffusive cross terms (:573, :582), reference order
     R ud, wu;
-    if constexpr (TPW == 1) {
+    if constexpr (UWREF) {
+      ud = x_dn[XO];
+      wu = x_up[XO + T::XARR];
+    } else if constexpr (TPW == 1) {
       ud = p_dn[LO + T::UO];
       wu = p_up[LO + T::WO];
     } else {
@@ -517,7 +628,14 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     G.PW[C0] = wq + wu;
 #endif
     G.UR[C0] = uq;
+#ifdef MPDATA_FAST_DIV
+    // UWREF: the ring holds w = 0 at level 1 instead of a zero per-lane constant KW (www(:,:,:,1) = 0, :586:
+    // both parts of W2 are then exact zeros there)
+    if constexpr (UWREF) G.WR[C0] = k_is_1 ? R(0) : wq;
+    else G.WR[C0] = wq;
+#else
     G.WR[C0] = wq;
+#endif
 
 #ifdef MPDWM_ABL_FIRSTPASS  // timing ablation only (wrong results): stop after the first (upwind) pass
     {
@@ -554,7 +672,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
           const R w2 = G.WR[C2];
           const R t1 = rabs(w2) - (w2 * w2) * IRHOW;
           const V x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
-          W2_2 = t1 * (S.F1[C2] - S.F1D[C2]) - (KW * (w2 * G.SU[C2])) * x4;  // = 2 x (:580-582); k = 1: 0
+          // (0.0625 on the non-constant factor: exact scaling, and no per-lane constant for the compiler to keep)
+          if constexpr (UWREF) W2_2 = t1 * (S.F1[C2] - S.F1D[C2]) - (IRHO * (w2 * G.SU[C2])) * (R(0.0625) * x4);
+          else W2_2 = t1 * (S.F1[C2] - S.F1D[C2]) - (KW * (w2 * G.SU[C2])) * x4;  // = 2 x (:580-582); k = 1: 0
 #else
           const V ad = andiff_s(S.F1D[C2], S.F1[C2], G.WR[C2], IRHOW);
           const V x = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
@@ -600,7 +720,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         const V mxd = DN_C(MXN_2);
         const V mnd = DN_C(MNN_2);
         const V W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
-        S3 = S3 + W3;  // :624
+        if constexpr (UWREF) S1 = S1 + W3;  // one accumulator (two registers that kernel does not have)
+        else S3 = S3 + W3;  // :624
         DW3_2 = UP_G(W3) - W3;
       }
     }
@@ -654,7 +775,24 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 // pair still in flight; seen as sporadic wrong columns with default-policy stores.)
 #define MPDWM_FLUSH_DEFERRED st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
 #define MPDWM_PAIR(PHA, PHB, SL, SLN, TAG, q, DMA)      \
-  if constexpr (TPW == 1) {                             \
+  if constexpr (UWREF) {                                \
+    /* own f and own share of u, w of this pair have landed (newer loads: f, uw of the next  \
+       pair and f of the one after: 3 x 2 instructions), every LDS read of the previous pair \
+       has returned; after the barrier the same holds for the whole workgroup: the pair's u, \
+       w are complete and the slot of the previous pair is free for the pair after next */   \
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("" ::: "memory");                      \
+    MPDWM_FLUSH_DEFERRED                                \
+    if (MPDWX_UW_POS == 0) dma_uw((((q) + 2) >> 1) + 2); \
+    step(PHA{}, SL{}, I0{}, TAG{}, (q), in_e);          \
+    asm volatile("" ::: "memory");                      \
+    if (MPDWX_UW_POS == 1) dma_uw((((q) + 2) >> 1) + 2); \
+    step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1, in_e);      \
+    asm volatile("" ::: "memory");                      \
+    if (MPDWX_UW_POS == 2) dma_uw((((q) + 2) >> 1) + 2); \
+    DMA((q) + 1);                                       \
+  } else if constexpr (TPW == 1) {                      \
     if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
     MPDWM_FLUSH_DEFERRED                                \
@@ -724,8 +862,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 
   if constexpr (TPW == 1) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
   {  // flux (:541-547, :624)
-    const V fl = S1 + S3;
-    if (lvl_ok) flux[pos] = first(fl);
+    const V fl = UWREF ? S1 : S1 + S3;
+    if (lvl_ok && tile_ok) flux[pos] = first(fl);
     if constexpr (TPW == 2)
       if (lvl_ok && has1) flux1[pos] = second(fl);
   }

@@ -127,6 +127,21 @@ bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags)
 #undef X
   return false;
 }
+// mpdata_plan_run_uw, one fp64 tracer: u, w read from the REFERENCE layout (a.u_ref, a.w_ref), f in
+// the plan layout; workgroups of 16 adjacent instances (16 / SLP waves)
+bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream) {
+#define X(LPS_)                                                                                        \
+  if (lps == LPS_) {                                                                                   \
+    constexpr int WPB = LPS_ / 4;                                                                      \
+    const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);                                    \
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS_, WPB, true, 1, true>), dim3(blocks),  \
+                       dim3(64 * WPB), 0, (hipStream_t)stream, a);                                     \
+    return true;                                                                                       \
+  }
+  X(8) X(16) X(32)   // (LPS = 64 would need 16 waves per workgroup at 128 VGPRs: not built, the caller converts)
+#undef X
+  return false;
+}
 // fp32 plans: two adjacent instances per lane (8-byte elements = pairs of fp32 values, packed
 // arithmetic); `a` describes the arrays in PAIRS (ncrms / 2 of them)
 bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stream, int flags) {
@@ -139,6 +154,7 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   a.flux = reinterpret_cast<v2::f32x2*>(a8.flux);
   a.ntiles = a8.ntiles; a.nx = a8.nx; a.nz = a8.nz; a.ntracers = a8.ntracers;
   a.tile_elems = a8.tile_elems; a.f_tstride = a8.f_tstride; a.flux_tstride = a8.flux_tstride; a.reverse = a8.reverse;
+  a.u_ref = nullptr; a.w_ref = nullptr; a.ncrms = 0;
 #define X(LPS_)                                \
   if (lps == LPS_) {                           \
     launch_wm_t<v2::f32x2, LPS_, 4>(a, stream, flags); \
@@ -181,6 +197,12 @@ const char* build_flags() {
 #endif
 #ifdef MPD_DPP_NOP1
          " MPD_DPP_NOP1"
+#endif
+#if MPDWX_UW_POS != 1
+         " MPDWX_UW_POS"
+#endif
+#if MPDWX_UW_AUX != 2
+         " MPDWX_UW_AUX"
 #endif
 #if MPD2_ST_AUX != 0
          " MPD2_ST_AUX"

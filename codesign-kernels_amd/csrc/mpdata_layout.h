@@ -32,4 +32,8 @@ struct MpdataLayoutJob {
 
 hipError_t mpdata_layout_convert(const MpdataLayoutJob& j, int elem_bytes, bool to_private, hipStream_t stream);
 
+// the split arrays (f, u, w: main_e > 0) column-walking: one workgroup per 64 (32) instances and array,
+// all columns; nj = 1, or 2 arrays of equal nlev in one launch (u and w of an import)
+hipError_t mpdata_layout_convert_cols(const MpdataLayoutJob* jobs, int nj, bool to_private, hipStream_t stream);
+
 #endif

@@ -73,7 +73,122 @@ __global__ void __launch_bounds__(256) wm_convert_kernel(const MpdataLayoutJob j
   }
 }
 
+// The same conversion for arrays with many columns (f, u, w): a workgroup owns TI consecutive
+// instances of one array (tracer) and walks through ALL its columns.  The private side of those
+// instances is then one contiguous region (TI/slp tiles) that this workgroup alone writes (reads),
+// column after column: the 48-byte remainders of neighbouring columns, which share 128-byte lines,
+// meet in L2 before the line is written back, and the DRAM pages stay open.  Column c+1 is fetched
+// into registers while column c goes out of the LDS tile.  Up to two arrays per launch (u and w of
+// an import: grid.z = array * ntr + tracer).
+struct MpdataLayoutJobs {
+  MpdataLayoutJob j[2];
+  int ntr_max;
+};
+template <typename R, int TI2, bool TO_PRIVATE>
+__global__ void __launch_bounds__(256) wm_convert_cols_kernel(const MpdataLayoutJobs js) {
+  extern __shared__ double lds_raw[];
+  constexpr int TP = TI2 + 1;
+  constexpr int NPT = 8;   // elements per thread and column: nlev * TI2 <= 8 * 256
+  const MpdataLayoutJob& j = js.j[blockIdx.z / js.ntr_max];
+  const int tr = blockIdx.z % js.ntr_max;
+  if (tr >= j.ntr) return;
+  R* tile = reinterpret_cast<R*>(lds_raw);   // [2][nlev][TP]
+  const int tid = threadIdx.x;
+  const long long sl0 = (long long)blockIdx.x * TI2;
+  const int nlev = j.nlev, slp = j.slp;
+  const int n = nlev * TI2;
+  const int tsz = nlev * TP;
+  R* ref = static_cast<R*>(j.ref) + (long long)tr * j.ref_tstride;
+  R* prv = static_cast<R*>(j.prv) + (long long)tr * j.prv_tstride;
+  const long long ninst_p = (long long)j.ntiles * slp;
+  const long long rem_e = j.chunk - j.main_e;
+
+  // per-thread element lists of the two sides (the same for every column)
+  long long ro[NPT], po[NPT];   // reference-side offset (column 0), private-side offset (column 0, + column stride below)
+  int rl[NPT], pl[NPT];         // LDS positions; -1: nothing
+  bool pmain[NPT];
+#pragma unroll
+  for (int e = 0; e < NPT; ++e) {
+    const int i = tid + e * 256;
+    rl[e] = pl[e] = -1; ro[e] = po[e] = 0; pmain[e] = true;
+    if (i < n) {
+      {  // reference side: i -> (level, instance): 8 * TI2 contiguous bytes per level
+        const int kk = i / TI2, t = i - kk * TI2;
+        long long sl = sl0 + t;
+        const bool in = sl < j.ncrms;
+        if (!in) sl = j.ncrms - 1;     // (import: the padding instances of the last tile are copies)
+        if (TO_PRIVATE || in) { rl[e] = kk * TP + t; ro[e] = sl + j.ncrms * (long long)kk * j.ref_levmul; }
+      }
+      {  // private side: i -> (instance, level): the chunk of a tile is contiguous
+        const int t = i / nlev, kk = i - t * nlev;
+        const long long inst = sl0 + t;
+        if (inst < ninst_p) {
+          const long long tl = inst / slp;
+          const long long el = (long long)(inst - tl * slp) * nlev + kk;
+          pl[e] = kk * TP + t;
+          pmain[e] = el < j.main_e;
+          po[e] = tl * j.prv_tile_stride + (pmain[e] ? el : (long long)j.ncol_p * j.main_e + (el - j.main_e));
+        }
+      }
+    }
+  }
+  const long long rcol = j.ncrms * j.ref_colmul;   // reference-side elements between columns
+  R v[NPT];
+  auto fetch = [&](const int cs) {
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) {
+      if (TO_PRIVATE) { if (rl[e] >= 0) v[e] = ref[ro[e] + rcol * cs]; }
+      else if (pl[e] >= 0) v[e] = prv[po[e] + (long long)(cs + j.prv_col0) * (pmain[e] ? j.main_e : rem_e)];
+    }
+  };
+  fetch(0);
+  for (int cs = 0; cs < j.ncols; ++cs) {
+    R* tb = tile + (cs & 1) * tsz;
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) {
+      const int l = TO_PRIVATE ? rl[e] : pl[e];
+      if (l >= 0) tb[l] = v[e];
+    }
+    __syncthreads();   // (two buffers: the previous column's readers are past the barrier of this one's predecessor)
+    if (cs + 1 < j.ncols) fetch(cs + 1);
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) {
+      if (TO_PRIVATE) { if (pl[e] >= 0) prv[po[e] + (long long)(cs + j.prv_col0) * (pmain[e] ? j.main_e : rem_e)] = tb[pl[e]]; }
+      else if (rl[e] >= 0) ref[ro[e] + rcol * cs] = tb[rl[e]];
+    }
+  }
+}
+
 }  // namespace
+
+// f, u, w (split arrays, many columns) in one launch; nj = 1 or 2 jobs of equal nlev / slp
+hipError_t mpdata_layout_convert_cols(const MpdataLayoutJob* jobs, int nj, bool to_private, hipStream_t stream) {
+  if (nj < 1 || nj > 2) return hipErrorInvalidValue;
+  MpdataLayoutJobs js;
+  js.ntr_max = 1;
+  long long nc = 0;
+  for (int i = 0; i < nj; ++i) {
+    const MpdataLayoutJob& j = jobs[i];
+    if (j.ncrms < 1 || j.ncols < 1 || j.ntr < 1 || j.nlev < 1 || j.main_e <= 0 || j.nlev != jobs[0].nlev) return hipErrorInvalidValue;
+    js.j[i] = j;
+    js.ntr_max = j.ntr > js.ntr_max ? j.ntr : js.ntr_max;
+    nc = j.ncrms > nc ? j.ncrms : nc;
+  }
+  if (nj == 1) js.j[1] = js.j[0];
+  const int nlev = jobs[0].nlev;
+  // instances per workgroup: 8 elements per thread and column
+  const int ti = nlev * 64 <= 2048 ? 64 : 32;
+  const dim3 grid((unsigned)((nc + ti - 1) / ti), 1, (unsigned)(nj * js.ntr_max)), block(256);
+  const size_t lds = (size_t)2 * nlev * (ti + 1) * 8;
+  if (ti == 64) {
+    if (to_private) hipLaunchKernelGGL((wm_convert_cols_kernel<double, 64, true>), grid, block, lds, stream, js);
+    else hipLaunchKernelGGL((wm_convert_cols_kernel<double, 64, false>), grid, block, lds, stream, js);
+  } else {
+    if (to_private) hipLaunchKernelGGL((wm_convert_cols_kernel<double, 32, true>), grid, block, lds, stream, js);
+    else hipLaunchKernelGGL((wm_convert_cols_kernel<double, 32, false>), grid, block, lds, stream, js);
+  }
+  return hipGetLastError();
+}
 
 hipError_t mpdata_layout_convert(const MpdataLayoutJob& j, int elem_bytes, bool to_private, hipStream_t stream) {
   if (j.ncrms < 1 || j.ncols < 1 || j.ntr < 1 || j.nlev < 1) return hipErrorInvalidValue;

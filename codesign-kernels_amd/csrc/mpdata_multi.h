@@ -14,6 +14,11 @@ __attribute__((visibility("hidden"))) int mpdata_multi_create(int64_t ncrms, int
                                                               const int* devices, int eb, mpdata_multi** out);
 __attribute__((visibility("hidden"))) int mpdata_multi_upload(mpdata_multi* m, const void* f, const void* u, const void* w,
                                                               const void* rho, const void* rhow, const void* adz, const void* flux);
+__attribute__((visibility("hidden"))) int mpdata_multi_scatter_device(mpdata_multi* m, const void* f, const void* u, const void* w,
+                                                                      const void* rho, const void* rhow, const void* adz,
+                                                                      const void* flux, int first, int count);
+__attribute__((visibility("hidden"))) int mpdata_multi_gather_device(mpdata_multi* m, void* f, void* flux, int first, int count);
+__attribute__((visibility("hidden"))) int mpdata_multi_ranks_seen(const mpdata_multi* m);
 __attribute__((visibility("hidden"))) int mpdata_multi_run(mpdata_multi* m, int first, int count);
 __attribute__((visibility("hidden"))) int mpdata_multi_sync(mpdata_multi* m);
 __attribute__((visibility("hidden"))) int mpdata_multi_download(mpdata_multi* m, void* f, void* flux);

@@ -138,25 +138,31 @@ int mpdata_set_plan_layout(int layout);            /* default for new plans; ret
 /* ---- 3b. One problem on several GPUs of the node.  No statement of the routine couples two
  * CRM instances (reference :505-637), so the ncrms axis is cut into `ngpus` contiguous blocks
  * (mpdata_shard_range), each GPU runs a plan of its own on its block and there is NO data-path
- * collective.  upload scatters the host arrays from GPU 0: H2D, pack kernel (a block is a
- * strided slab: `sl` is the fastest axis), ncclSend / ncclRecv in one group -- RCCL over xGMI,
- * one direct link per peer; download gathers f and flux the same way.  This replaces the
- * reference's `!$acc update device / update host` (:107, :241-242).  One host thread drives all
- * devices.  The handle is an ordinary plan: upload, run, run_tracers, sync, download,
- * last_kernel_ms (slowest GPU) and destroy work on it; results are bitwise those of a
- * single-GPU plan.  MPDATA_MULTI_XFER = rccl (default) | p2p (hipMemcpyPeerAsync) | direct
- * (every GPU copies its slab from / to the host itself, no root). */
+ * collective.  What replaces the reference's `!$acc update device / update host` (:107,
+ * :241-242) depends on where the global arrays live:
+ *   on the ROOT GPU (shard 0's device; mpdata_plan_import_device / _export_device on the
+ *   multi-GPU plan, full-width reference-layout arrays): scatter = pack kernel (a block is a
+ *   strided slab: `sl` is the fastest axis) + ncclSend / ncclRecv in ONE group -- RCCL over
+ *   xGMI, one direct link per peer --, gather the reverse;
+ *   on the HOST (mpdata_plan_upload / _download): every GPU copies its own slab ("direct": all
+ *   PCIe links in parallel, nothing funnels through the root's one link).
+ * One host thread drives all devices; the arrays of one transfer are queued back to back and
+ * synchronised once.  The handle is an ordinary plan: upload, import_device, run, run_tracers,
+ * sync, download, export_device, last_kernel_ms (slowest GPU) and destroy work on it; results
+ * are bitwise those of a single-GPU plan.  MPDATA_MULTI_XFER = rccl | p2p (hipMemcpyPeerAsync)
+ * | direct forces one transport for both origins (direct: host arrays only). */
 int mpdata_plan_create_multi(int64_t ncrms, int nx, int nz, int ntracers, int ngpus, mpdata_plan** plan);
 int mpdata_plan_create_multi_devices(int64_t ncrms, int nx, int nz, int ntracers, int ngpus,
                                      const int* devices, mpdata_plan** plan); /* explicit HIP ordinals */
 void mpdata_shard_range(int64_t ncrms, int ngpus, int g, int64_t* sl0, int64_t* nloc); /* block of GPU g */
 int mpdata_plan_ngpus(const mpdata_plan* plan);
+int mpdata_plan_ranks_seen(const mpdata_plan* plan); /* ncclCommCount of the plan's communicator; 0: none */
 int mpdata_plan_shard(const mpdata_plan* plan, int g, int* device, int64_t* sl0, int64_t* nloc);
 /* the single-device plan of GPU g (owned by the multi-GPU plan: do not destroy): for callers whose
  * shard already lives on that device -- mpdata_plan_import_device / _export_device on it */
 mpdata_plan* mpdata_plan_shard_plan(mpdata_plan* plan, int g);
 /* wall seconds and bytes per peer link of the last upload (scatter) / download (gather);
- * transport: 0 rccl, 1 p2p, 2 direct */
+ * transport (of the last transfer): 0 rccl, 1 p2p, 2 direct */
 int mpdata_plan_transfer_stats(const mpdata_plan* plan, double* scatter_s, double* gather_s,
                                int64_t* scatter_bytes_per_peer, int64_t* gather_bytes_per_peer,
                                int* transport);

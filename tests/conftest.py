@@ -29,6 +29,10 @@ def _libraries_built():
     libs = [os.path.join(pkg, n) for n in ("libmpdata_hip.so", "libbwk_hip.so", "libnlk_hip.so")]
     if not all(os.path.exists(p) for p in libs) and shutil.which("hipcc"):
         subprocess.run(["make", "-C", os.path.join(pkg, "csrc"), "-j4"], check=True, stdout=subprocess.DEVNULL)
+    if shutil.which("hipcc") and all(os.path.exists(p) for p in libs) and \
+            not os.path.exists(os.path.join(ROOT, "tests", "stubs", "libmpdata_hip_fakerccl.so")):
+        # the test-only link of the product objects against the recording RCCL stand-in (tests/stubs)
+        subprocess.run(["make", "-C", os.path.join(pkg, "csrc"), "fakerccl"], check=True, stdout=subprocess.DEVNULL)
     fdir = os.path.join(pkg, "fortran")
     if shutil.which("amdflang") and all(os.path.exists(p) for p in libs):
         for exe, extra in (("advect", []), ("advect_sp", ["single=1"])):

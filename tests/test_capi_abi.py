@@ -97,8 +97,12 @@ def test_default_kernels_do_not_spill():
                 seen += 1
                 assert scratch == 0, f"{name} spills {scratch} bytes/lane"
                 # (the one-instance-per-wave wave-major kernels, nz 33..64, are built for 3; the
-                #  two-tracers-per-wave batch kernels, template argument TPW = 2, for 2)
-                want = 2 if re.search(r"wm_kernelI\S*ELb0ELi2EEE", name) else \
+                #  two-tracers-per-wave batch kernels, template argument TPW = 2, for 2; the EXACT build
+                #  of the kernel that reads u, w from the reference layout, last argument UWREF = true,
+                #  is the parity variant of that kernel and runs one 8-wave workgroup per CU: 2)
+                uwref = re.search(r"wm_kernelI\S*ELb1ELi1ELb1EEE", name) is not None
+                want = 2 if re.search(r"wm_kernelI\S*ELb0ELi2ELb0EEE", name) else \
+                    2 if (uwref and "mpdata_exact" in name) else \
                     3 if ("wm_kernelIdLi64" in name or "wm_kernelIDv2_fLi64" in name) else 4
                 assert occ >= want, f"{name} occupancy {occ} waves/SIMD"
     assert seen >= 8 + 16   # x-march tilings + wave-major kernels (4 LPS x 2 fetch modes), both variants
