@@ -543,6 +543,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    # who is really there: ranks of the process group (= ncclCommCount of the RCCL communicator behind it)
+    # and the HIP device every rank sits on
+    ranks_seen, devices_seen = 1, [local]
+    if world > 1:
+        ranks_seen = dist.get_world_size()
+        dv = torch.tensor([torch.cuda.current_device()], dtype=torch.int32, device="cpu" if rehearsal else dev)
+        allv = [torch.zeros_like(dv) for _ in range(world)]
+        dist.all_gather(allv, dv)
+        devices_seen = [int(t.item()) for t in allv]
     M.set_variant(M.VARIANT_FAST if args.variant == "fast" else M.VARIANT_EXACT)
     M.set_tile(args.tile)
     serp = 1 if args.serpentine else 0
@@ -593,7 +602,8 @@ def main():
                                "launch was touched by the previous one)" if not info["uw_shared_across_steps"] else
                                "NO: the field sets share u, w",
                        "prewarm_ms": args.prewarm_ms,
-                       "parallelism": f"ncrms-sharded x{world}, no data-path collective"},
+                       "parallelism": f"ncrms-sharded x{world}, no data-path collective",
+                       "ranks_seen": ranks_seen, "devices_seen": devices_seen},
             "roofline": roofline_block(alg_bytes, kms, {
                 "traffic": traffic,
                 "traffic_source": None if traffic is None else "profiles/hbm_traffic.json[%s]: PMC passes of "
@@ -664,6 +674,12 @@ def main():
             if vi:   # second ceiling (SURVEY.md 7 hard part 3): fp64 VALU issue
                 t_valu = vi[0] / VALU_PEAK_WAVE_INSTR_PER_S
                 rb["valu_frac"] = t_valu / (ka * 1e-3)
+                rb["valu_source"] = "recorded profile (%s): SQ_INSTS_VALU cannot be read in an un-profiled run; NOT a " \
+                                    "measurement of this run" % vi[1]
+                t_hbm = ab / (HBM_PEAK_GBS * 1e9)
+                rb["binding_floor_frac"] = max(t_hbm, t_valu) / (ka * 1e-3)
+                rb["binding_floor_note"] = "max(algorithmic bytes / 8 TB/s, VALU instructions / measured issue peak) / kernel " \
+                                           "time: how close the run is to whichever of its two ceilings binds (here: VALU)"
                 rb["valu_note"] = "VALU instructions per launch (%s, SQ counters of the builder's box) / measured fp64 " \
                                   "VALU issue peak (tools/valu_rate.hip: 33e12 lane-ops/s, at the 2.0 GHz that " \
                                   "microbenchmark sustains; this kernel runs at 1.7-1.85 GHz, power-limited) / kernel time" % vi[1]

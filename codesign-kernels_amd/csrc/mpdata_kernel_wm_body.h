@@ -191,6 +191,11 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   static_assert(TPW == 1 || (TPW == 2 && !STREAM), "two tracers per wave: batch form only");
   static_assert(!UWREF || (STREAM && TPW == 1), "u, w from the reference layout: one tracer per launch");
   using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
+#ifdef MPDWM_EXTREMA_OLD
+  constexpr bool XNEW = false;
+#else
+  constexpr bool XNEW = TPW == 2;   // the 7-operation extrema (stage A below): where the registers allow it
+#endif
   constexpr int SLP = T::SLP, RB = (int)sizeof(R);
   __shared__ R lds[T::LDS_ELEMS];
 
@@ -575,6 +580,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 
     // ================= stage A =================================================
     V U1q = ZV, DW1q = ZV, f1_1 = ZV, F1D_1 = ZV, F1U_1 = ZV, MX0_1 = ZV, MN0_1 = ZV;
+    [[maybe_unused]] V G1mx = F0p, G1mn = F0p;   // G of column q-1 (an inactive step: never used by a valid star)
     if (FULL || (q >= -1 && q <= nx + 3)) {
       U1q = upwind(uq, F0p, f0q);  // :532
       if (FULL || q <= nx + 2) {
@@ -586,8 +592,21 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         f1_1 = F0p - ((U1q - S.U1[C1]) + S.DW1[C1] * IADZ) * IRHO;  // :557, column q-1
         F1D_1 = DN_C(f1_1);
         F1U_1 = UP_C(f1_1);
+        if constexpr (!XNEW) {
         MX0_1 = dmax(S.PMX[C1], f0q);  // :521-522 complete for column q-1
         MN0_1 = dmin(S.PMN[C1], f0q);
+        } else {
+        // Two tracers per wave (256 VGPRs; the one-tracer kernels have no room for G across the stages):
+        // extrema of BOTH passes at once (:521-522 and :596-597 take the max / min of the same five
+        // points of f0 and of f1 -- the extremum of a set does not depend on the order): with
+        //   G(i) = max(f0(i,k), f1(i,k)),  A(i) = max(f0(i,kb), f0(i,kc), G(i-1)),
+        //   P(i) = max(A(i), f1(i,kb), f1(i,kc), G(i))    the star of column i is  max(P(i), G(i+1)):
+        // 7 operations per column instead of 9, each for max and min.  PMX / PMN carry A, MX0 / MN0 carry P.
+        G1mx = dmax(F0p, f1_1);
+        G1mn = dmin(F0p, f1_1);
+        MX0_1 = dmax(dmax(dmax(S.PMX[C1], F1D_1), F1U_1), G1mx);   // P of column q-1
+        MN0_1 = dmin(dmin(dmin(S.PMN[C1], F1D_1), F1U_1), G1mn);
+        }
         // the last two halo columns (nx+1, nx+2) keep this first-pass value (:557) and no later
         // step finishes them: store them now (their input values are already in the LDS ring)
         if (!FULL && q - 1 >= nx + 1) st_col(q - 1 <= nx + 2, q + 1, f1_1, std::integral_constant<int, 2>{});
@@ -601,8 +620,13 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     S.MX0[C1] = MX0_1;
     S.MN0[C1] = MN0_1;
     // :521-522 for column q without its f(ic) term
-    S.PMX[C0] = dmax(dmax(dmax(F0p, f0d), f0u), f0q);
-    S.PMN[C0] = dmin(dmin(dmin(F0p, f0d), f0u), f0q);
+    if constexpr (!XNEW) {
+      S.PMX[C0] = dmax(dmax(dmax(F0p, f0d), f0u), f0q);
+      S.PMN[C0] = dmin(dmin(dmin(F0p, f0d), f0u), f0q);
+    } else {
+      S.PMX[C0] = dmax(dmax(f0d, f0u), G1mx);   // A of column q
+      S.PMN[C0] = dmin(dmin(f0d, f0u), G1mn);
+    }
     S.F0[C0] = f0q;
 
     // u / w sums for the antidiffusive cross terms (:573, :582), reference order
@@ -684,8 +708,14 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         }
         const V W2u = UP_C(W2_2);
         // :596-597
-        const V mx1 = dmax(dmax(dmax(dmax(dmax(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MX0[C2]);
-        const V mn1 = dmin(dmin(dmin(dmin(dmin(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MN0[C2]);
+        V mx1, mn1;
+        if constexpr (!XNEW) {
+          mx1 = dmax(dmax(dmax(dmax(dmax(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MX0[C2]);
+          mn1 = dmin(dmin(dmin(dmin(dmin(S.F1[C3], f1_1), S.F1D[C2]), S.F1U[C2]), S.F1[C2]), S.MN0[C2]);
+        } else {
+          mx1 = dmax(S.MX0[C2], G1mx);   // star of column q-2: P(q-2) and G(q-1)
+          mn1 = dmin(S.MN0[C2], G1mn);
+        }
         // :606-609
         W2p = pp(W2_2);
         W2n = pn(W2_2);

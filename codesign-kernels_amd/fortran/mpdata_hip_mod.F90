@@ -17,6 +17,7 @@ module mpdata_hip_mod
   private
   public :: advect_scalar2D, advect_resident_begin, advect_resident_run, advect_resident_end
   public :: mpdata_set_variant, mpdata_check, advect_transfer_stats
+  public :: advect_device_problem_run
 
   ! the C entry points that carry reals exist per precision (include/mpdata_hip.h sections 1-3
   ! and 6); `make single=1` (-DMPDATA_SINGLE) binds the fp32 ones, rp = c_float
@@ -95,6 +96,44 @@ module mpdata_hip_mod
     end function
     type(c_ptr) function mpdata_last_error_c() bind(C, name="mpdata_last_error")
       import :: c_ptr
+    end function
+    ! ---- device-resident mode: the global arrays live on the root GPU (include/mpdata_hip.h 3, 3b, 4, 4b)
+    integer(c_int) function mpdata_device_alloc_c(ptr, bytes) bind(C, name="mpdata_device_alloc")
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr) :: ptr
+      integer(c_int64_t), value :: bytes
+    end function
+    integer(c_int) function mpdata_device_free_c(ptr) bind(C, name="mpdata_device_free")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ptr
+    end function
+    integer(c_int) function mpdata_device_sum_c(a, n, blk, stride, s) bind(C, name="mpdata_device_sum")
+      import :: c_int, c_int64_t, c_ptr, c_double
+      type(c_ptr), value :: a
+      integer(c_int64_t), value :: n, blk, stride
+      real(c_double) :: s
+    end function
+    integer(c_int) function mpdata_fill_synthetic_device_c(a, sid, rows, ncrms_global, sl0, nloc, seed, dist, stream) &
+        bind(C, name="mpdata_fill_synthetic_device")
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: a, stream
+      integer(c_int), value :: sid, dist
+      integer(c_int64_t), value :: rows, ncrms_global, sl0, nloc, seed
+    end function
+    integer(c_int) function mpdata_plan_import_device_c(plan, f, u, w, rho, rhow, adz, flux, first, n) &
+        bind(C, name="mpdata_plan_import_device")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: plan, f, u, w, rho, rhow, adz, flux
+      integer(c_int), value :: first, n
+    end function
+    integer(c_int) function mpdata_plan_export_device_c(plan, f, flux, first, n) bind(C, name="mpdata_plan_export_device")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: plan, f, flux
+      integer(c_int), value :: first, n
+    end function
+    integer(c_int) function mpdata_plan_ranks_seen_c(plan) bind(C, name="mpdata_plan_ranks_seen")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: plan
     end function
   end interface
 
@@ -177,6 +216,63 @@ contains
     scatter_s = last_scatter_s; gather_s = last_gather_s
     scatter_bytes = last_scatter_bytes; gather_bytes = last_gather_bytes
   end subroutine advect_transfer_stats
+
+  !> The whole sequence with the GLOBAL arrays resident on the root GPU instead of the host: the
+  !! inputs are generated there (mpdata_fill_synthetic_device: the law init() uses, element for
+  !! element), handed to the plan by mpdata_plan_import_device -- for ngpus > 1 that is the scatter
+  !! over RCCL / xGMI, the replacement of the reference's `update device` (:107) --, advected (the
+  !! reference's timed region, :110-:238), gathered back (`update host`, :241) and summed on the
+  !! device.  No host array of the problem's size exists: BASELINE.json configs[4] (ncrms = 524288 x
+  !! 25 tracers: 107.6 GB of f) runs from a host with a few GB.  fp64 only.
+  subroutine advect_device_problem_run(seed, dist, kernel_ms, wall_s, sum_f, sum_flux, ranks)
+    integer(c_int64_t), intent(in) :: seed
+    integer, intent(in) :: dist
+    real(c_double), intent(out) :: kernel_ms, wall_s, sum_f, sum_flux
+    integer, intent(out) :: ranks
+#ifdef MPDATA_SINGLE
+    write(*,*) 'the device-resident mode is fp64'
+    error stop 1
+#else
+    type(c_ptr) :: plan, d(0:6)
+    integer(c_int64_t) :: rows(0:6), n, nf, nx1
+    integer(8) :: t1, t2, tr
+    integer :: i
+    ! generator ids (the reference's fill order, :654-660): 0 adz, 1 f, 2 u, 3 w, 4 rho, 5 rhow, 6 flux
+    rows = [ int(nzm, 8), int(nx+6, 8)*nzm*ntracers, int(nx+5, 8)*nzm, int(nx+4, 8)*nz, int(nzm, 8), int(nz, 8), &
+             int(nz, 8)*ntracers ]
+    do i = 0, 6
+      call mpdata_check(mpdata_device_alloc_c(d(i), rows(i)*nslices*8_8), 'mpdata_device_alloc')
+      call mpdata_check(mpdata_fill_synthetic_device_c(d(i), int(i, c_int), rows(i), nslices, 0_8, nslices, seed, &
+                                                       int(dist, c_int), c_null_ptr), 'mpdata_fill_synthetic_device')
+    end do
+    call create_plan(plan)
+    ranks = mpdata_plan_ranks_seen_c(plan)
+    ! scatter (ngpus > 1) / layout entry; twice: the first run is the warm-up the reference's first
+    ! OpenACC call pays as well, the second import restores the inputs for the timed run
+    do i = 1, 2
+      call mpdata_check(mpdata_plan_import_device_c(plan, d(1), d(2), d(3), d(4), d(5), d(0), d(6), 0_c_int, &
+                                                    int(ntracers, c_int)), 'mpdata_plan_import_device')
+      call mpdata_check(mpdata_plan_sync_c(plan), 'mpdata_plan_sync')
+      call system_clock(t1)
+      call mpdata_check(mpdata_plan_run_c(plan), 'mpdata_plan_run')
+      call mpdata_check(mpdata_plan_sync_c(plan), 'mpdata_plan_sync')
+      call system_clock(t2, tr)
+    end do
+    wall_s = dble(t2-t1)/dble(tr)
+    call mpdata_check(mpdata_plan_last_kernel_ms_c(plan, kernel_ms), 'mpdata_plan_last_kernel_ms')
+    call mpdata_check(mpdata_plan_export_device_c(plan, d(1), d(6), 0_c_int, int(ntracers, c_int)), 'mpdata_plan_export_device')
+    call mpdata_check(mpdata_plan_sync_c(plan), 'mpdata_plan_sync')
+    call record_stats(plan)
+    nf = rows(1)*nslices
+    call mpdata_check(mpdata_device_sum_c(d(1), nf, nf, nf, sum_f), 'mpdata_device_sum')
+    n = rows(6)*nslices; nx1 = int(nz, 8)*nslices     ! flux(:,1:nzm,:) -- level nz is never written (:541, :624)
+    call mpdata_check(mpdata_device_sum_c(d(6), n, int(nzm, 8)*nslices, nx1, sum_flux), 'mpdata_device_sum')
+    call mpdata_check(mpdata_plan_destroy_c(plan), 'mpdata_plan_destroy')
+    do i = 0, 6
+      call mpdata_check(mpdata_device_free_c(d(i)), 'mpdata_device_free')
+    end do
+#endif
+  end subroutine advect_device_problem_run
 
   !> Device-resident form = the reference's timed region (:105-110, :237-242):
   !! begin = `enter data` + `update device`; run = the kernels + `wait`;

@@ -1,11 +1,18 @@
 !> Driver of the MI355X build: the role of the reference's `program test_advect`
 !! (mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:3-68, :645-683).
 !!
-!!   ./advect [ncrms nx nz [dist [variant [dumpfile [reffile [ntracers [ngpus]]]]]]]
+!!   ./advect [ncrms nx nz [dist [variant [dumpfile [reffile [ntracers [ngpus [mode]]]]]]]]
 !!   ./advect file.nml        sizes from a namelist (the reference's other mini-app is configured
 !!                            this way, nested_loops/nested.nml:1-7):
 !!                            &advect_nml ncrms=65536, nx=32, nz=28, dist=1, variant=1, ntracers=25,
-!!                                        ngpus=8, dumpfile='-', reffile='-' /
+!!                                        ngpus=8, dumpfile='-', reffile='-', mode='auto' /
+!!
+!! mode = host   : global arrays on the HOST (the reference's own situation: init on the host, `update
+!!                 device`, kernels, `update host`), everything below;
+!!        device : global arrays generated and kept on the ROOT GPU, scattered / gathered from there
+!!                 (RCCL over xGMI for ngpus > 1), checksums on the device -- no host array of the
+!!                 problem's size: BASELINE.json configs[4] (524288 x 25 tracers, 107.6 GB of f);
+!!        auto   : device when one copy of f exceeds 4 GiB, else host (default).
 !!
 !! ntracers > 1: the tracer-batched call (same u,w,rho,rhow,adz for every tracer, tracer index
 !! slowest); ngpus > 1: the ncrms axis sharded over the GPUs of the node, inputs scattered and
@@ -32,18 +39,20 @@ program test_advect
   real(rp), allocatable :: f(:,:,:,:,:), u(:,:,:,:), w(:,:,:,:), rho(:,:), rhow(:,:), flux(:,:,:)
   real(rp), allocatable :: f_in(:,:,:,:,:)
   integer(c_int64_t) :: n_arg
-  integer :: nx_arg, nz_arg, dist, variant, rc, nt_arg, ng_arg
+  integer :: nx_arg, nz_arg, dist, variant, rc, nt_arg, ng_arg, ranks
   character(len=512) :: arg, dumpfile, reffile
+  character(len=16) :: mode
+  real(c_double) :: d_kms, d_wall, d_sumf, d_sumflux
   integer(8) :: t1, t2, tr
   real(rp) :: kms
   real(c_double) :: sc_s, ga_s
   integer(c_int64_t) :: sc_b, ga_b
 
   n_arg = 64; nx_arg = 32; nz_arg = 28; dist = 1; variant = 0; dumpfile = ''; reffile = ''
-  nt_arg = 1; ng_arg = 1
+  nt_arg = 1; ng_arg = 1; mode = 'auto'
   call get_command_argument(1, arg)
   if (command_argument_count() == 1 .and. index(arg, '.nml') > 0) then
-    call read_namelist(trim(arg), n_arg, nx_arg, nz_arg, dist, variant, nt_arg, ng_arg, dumpfile, reffile)
+    call read_namelist(trim(arg), n_arg, nx_arg, nz_arg, dist, variant, nt_arg, ng_arg, dumpfile, reffile, mode)
   end if
   if (command_argument_count() >= 3) then
     call get_command_argument(1, arg); read(arg, *) n_arg
@@ -64,10 +73,30 @@ program test_advect
   if (command_argument_count() >= 9) then
     call get_command_argument(9, arg); read(arg, *) ng_arg
   end if
+  if (command_argument_count() >= 10) call get_command_argument(10, mode)
   if (trim(dumpfile) == '-') dumpfile = ''
   if (trim(reffile) == '-') reffile = ''
 
   call grid_set(n_arg, nx_arg, nz_arg, nt_arg, ng_arg)
+  if (trim(mode) == 'auto') then
+    mode = 'host'
+    if (nslices*int(nx+6, 8)*int(nzm, 8)*int(ntracers, 8)*8_8 > 4294967296_8) mode = 'device'
+  end if
+  if (trim(mode) == 'device') then
+    ! ---- the problem lives on the root GPU: no host array of its size (see the header)
+    write(*,*) 'ncrms, nx, nz, ntracers, ngpus: ', nslices, nx, nz, ntracers, ngpus
+    write(*,*) 'mode: device (global arrays generated and kept on the root GPU)'
+    rc = mpdata_set_variant(int(variant, c_int))
+    call advect_device_problem_run(100_8, dist, d_kms, d_wall, d_sumf, d_sumflux, ranks)
+    write(*,*) 'RCCL ranks seen (ncclCommCount; 0 = no communicator): ', ranks
+    write(*,*) 'HIP Timing: ', d_wall
+    write(*,*) 'HIP kernel (hipEvent) seconds: ', d_kms*1.0d-3
+    call print_transfer_stats()
+    write(*,*) 'cell updates per call: ', nslices*int(nx,8)*int(nzm,8)*int(ntracers,8)
+    write(*,*) 'checksum f   : ', d_sumf
+    write(*,*) 'checksum flux: ', d_sumflux
+    stop
+  end if
   allocate(f(nslices, -2:nx+3, 1, nzm, ntracers), u(nslices, -1:nx+3, 1, nzm), w(nslices, -1:nx+2, 1, nz))
   allocate(rho(nslices, nzm), rhow(nslices, nz), flux(nslices, nz, ntracers))
   write(*,*) 'ncrms, nx, nz, ntracers, ngpus: ', nslices, nx, nz, ntracers, ngpus
@@ -113,22 +142,24 @@ contains
 
   !> the namelist form of the command line; names as in BASELINE.json / the C-ABI.  Values not
   !! named in the file keep the defaults passed in.
-  subroutine read_namelist(path, o_ncrms, o_nx, o_nz, o_dist, o_variant, o_ntracers, o_ngpus, o_dump, o_ref)
+  subroutine read_namelist(path, o_ncrms, o_nx, o_nz, o_dist, o_variant, o_ntracers, o_ngpus, o_dump, o_ref, o_mode)
     character(*), intent(in) :: path
     integer(c_int64_t), intent(inout) :: o_ncrms
     integer, intent(inout) :: o_nx, o_nz, o_dist, o_variant, o_ntracers, o_ngpus
     character(len=512), intent(inout) :: o_dump, o_ref
+    character(len=16), intent(inout) :: o_mode
     integer(c_int64_t) :: ncrms
     integer :: nx, nz, dist, variant, ntracers, ngpus, iu
     character(len=512) :: dumpfile, reffile
-    namelist /advect_nml/ ncrms, nx, nz, dist, variant, ntracers, ngpus, dumpfile, reffile
+    character(len=16) :: mode
+    namelist /advect_nml/ ncrms, nx, nz, dist, variant, ntracers, ngpus, dumpfile, reffile, mode
     ncrms = o_ncrms; nx = o_nx; nz = o_nz; dist = o_dist; variant = o_variant
-    ntracers = o_ntracers; ngpus = o_ngpus; dumpfile = o_dump; reffile = o_ref
+    ntracers = o_ntracers; ngpus = o_ngpus; dumpfile = o_dump; reffile = o_ref; mode = o_mode
     open(newunit=iu, file=path, status='old', action='read')
     read(iu, nml=advect_nml)
     close(iu)
     o_ncrms = ncrms; o_nx = nx; o_nz = nz; o_dist = dist; o_variant = variant
-    o_ntracers = ntracers; o_ngpus = ngpus; o_dump = dumpfile; o_ref = reffile
+    o_ntracers = ntracers; o_ngpus = ngpus; o_dump = dumpfile; o_ref = reffile; o_mode = mode
   end subroutine read_namelist
 
   subroutine print_transfer_stats()

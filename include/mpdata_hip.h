@@ -177,6 +177,15 @@ int mpdata_fill_synthetic_device(double* a, int sid, int64_t rows, int64_t ncrms
                                  int64_t sl0, int64_t nloc, uint64_t seed, int dist,
                                  void* stream);
 
+/* ---- 4b. A minimal device workspace for hosts that cannot call HIP themselves (the Fortran
+ * driver's device-resident mode: the global arrays are generated on the root GPU with
+ * mpdata_fill_synthetic_device and handed to mpdata_plan_import_device).  mpdata_device_sum: the sum
+ * of the elements j < n with (j mod stride) < block (block = stride = n: all of them), in a fixed
+ * order (a checksum, reproducible run to run). */
+int mpdata_device_alloc(void** ptr, int64_t bytes);   /* on the current device */
+int mpdata_device_free(void* ptr);
+int mpdata_device_sum(const double* a, int64_t n, int64_t block, int64_t stride, double* sum);
+
 /* ---- 5. Shard pack/unpack for the multi-GPU scatter/gather (device
  * pointers).  A shard [sl0, sl0+nloc) of an array with leading dimension
  * ncrms is a strided slab; pack makes it contiguous (leading dimension
@@ -239,8 +248,9 @@ int mpdata_get_variant(void);
 int mpdata_set_serpentine(int on);
 /* Test switches of the wave-major launch (bit 0: the batch form of the kernel for one tracer as
  * well, bit 1: one tracer per wave in tracer batches, bit 2: an odd last tracer stays in the
- * two-tracer launch; MPDATA_WM_NOSTREAM / MPDATA_WM_TPW1 / MPDATA_WM_NOSPLIT in the environment
- * set the initial value); flags < 0 only queries.  Returns the previous value. */
+ * two-tracer launch, bit 3: its one-tracer kernel runs behind the batch kernel instead of beside
+ * it on a second stream; MPDATA_WM_NOSTREAM / _TPW1 / _NOSPLIT / _NOSIDE in the environment set
+ * the initial value); flags < 0 only queries.  Returns the previous value. */
 int mpdata_set_wm_flags(int flags);
 int mpdata_set_tile(int tile);            /* kernel tiling id; -1 = default */
 int mpdata_set_debug_buffer(void* dev_ptr); /* diagnostic builds only: clock-stamp buffer */
