@@ -52,7 +52,6 @@ typedef MpdataWmArgsT<double> MpdataWmArgs;
 #define MPDATA_WMF_NOSTREAM 1   // run the batch form of the kernel on a single tracer as well
 #define MPDATA_WMF_TPW1 2       // tracer batches: one tracer per wave
 #define MPDATA_WMF_NOSPLIT 4    // an odd last tracer stays in the two-tracer launch
-#define MPDATA_WMF_NOSIDE 8     // an odd last tracer's one-tracer kernel runs BEHIND the batch, not beside it
 
 // One tiling of the kernel template (W columns per thread, SPW strips per
 // wave, NWV waves per workgroup).

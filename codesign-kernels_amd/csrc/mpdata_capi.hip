@@ -309,14 +309,14 @@ int mpdata_advect_scalar2d_f32_device(int64_t ncrms, int nx, int nz, int ntracer
 // mpdata_kernel_wm_body.h and convert in upload / download / import / export; other plans
 // (fp32; nz > 64) keep the reference layout and run the x-/k-marching kernels.
 namespace mpdata_exact {
-bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags, void* side, void* fork, void* join);
-bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags, void* side, void* fork, void* join);
+bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
+bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
 bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream);
 }
 namespace mpdata_fast {
 bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream);
-bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags, void* side, void* fork, void* join);
-bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags, void* side, void* fork, void* join);
+bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
+bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
 }
 
 namespace {
@@ -346,7 +346,7 @@ int g_wm_flags = -1;
 int wm_flags() {
   if (g_wm_flags < 0)
     g_wm_flags = (getenv("MPDATA_WM_NOSTREAM") ? MPDATA_WMF_NOSTREAM : 0) | (getenv("MPDATA_WM_TPW1") ? MPDATA_WMF_TPW1 : 0) |
-                 (getenv("MPDATA_WM_NOSPLIT") ? MPDATA_WMF_NOSPLIT : 0) | (getenv("MPDATA_WM_NOSIDE") ? MPDATA_WMF_NOSIDE : 0);
+                 (getenv("MPDATA_WM_NOSPLIT") ? MPDATA_WMF_NOSPLIT : 0);
   return g_wm_flags;
 }
 int wm_wpb() { return 4; }  // waves (tiles) per workgroup of the wave-major kernels
@@ -384,8 +384,6 @@ struct mpdata_plan {
   hipStream_t stream;
   bool own_stream;
   hipEvent_t ev0, ev1;
-  hipStream_t side;              // the one-tracer kernel of an odd last tracer runs here, beside the batch kernel
-  hipEvent_t ev_fork, ev_join;
   bool uploaded, ran;
   unsigned runs;   // launches so far (serpentine tile order)
   mpdata_multi* multi;  // != null: a multi-GPU plan (mpdata_multi.hip); nothing else above is used
@@ -735,17 +733,10 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
       return 0;
     }
     const int fl = wm_flags();
-    // an odd tracer count > 1: the last tracer's kernel goes to the plan's side stream (created on first use)
-    if (count > 1 && (count & 1) && !p->side && !(fl & (MPDATA_WMF_NOSIDE | MPDATA_WMF_NOSPLIT | MPDATA_WMF_TPW1))) {
-      HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-    }
-    void *sd = (void*)p->side, *ef = (void*)p->ev_fork, *ej = (void*)p->ev_join;
-    const bool ok = p->eb == 8 ? (fast ? mpdata_fast::launch_wm(p->lps, p->wpb, a, (void*)p->stream, fl, sd, ef, ej)
-                                       : mpdata_exact::launch_wm(p->lps, p->wpb, a, (void*)p->stream, fl, sd, ef, ej))
-                               : (fast ? mpdata_fast::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream, fl, sd, ef, ej)
-                                       : mpdata_exact::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream, fl, sd, ef, ej));
+    const bool ok = p->eb == 8 ? (fast ? mpdata_fast::launch_wm(p->lps, p->wpb, a, (void*)p->stream, fl)
+                                       : mpdata_exact::launch_wm(p->lps, p->wpb, a, (void*)p->stream, fl))
+                               : (fast ? mpdata_fast::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream, fl)
+                                       : mpdata_exact::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream, fl));
     if (!ok) return set_err(MPDATA_EINVAL, "wave-major kernel LPS=%d WPB=%d not instantiated", p->lps, p->wpb);
     HIP_TRY(hipGetLastError());
   } else {
@@ -948,9 +939,6 @@ int mpdata_plan_destroy(mpdata_plan* p) {
   void* bufs[7] = {p->pf, p->pu, p->pw, p->pkc, p->pflux, p->stage, p->flux_ref};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
-  if (p->side) (void)hipStreamDestroy(p->side);
-  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
@@ -1225,7 +1213,7 @@ int mpdata_set_variant(int v) {
 int mpdata_get_variant(void) { return variant(); }
 int mpdata_set_wm_flags(int flags) {
   const int prev = wm_flags();
-  if (flags >= 0) g_wm_flags = flags & (MPDATA_WMF_NOSTREAM | MPDATA_WMF_TPW1 | MPDATA_WMF_NOSPLIT | MPDATA_WMF_NOSIDE);
+  if (flags >= 0) g_wm_flags = flags & (MPDATA_WMF_NOSTREAM | MPDATA_WMF_TPW1 | MPDATA_WMF_NOSPLIT);
   return prev;
 }
 int mpdata_set_serpentine(int on) {

@@ -73,16 +73,8 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
 // wave-major kernels (mpdata_kernel_wm_body.h, the plan API): LPS = lanes per instance (>= nz),
 // WPB = waves per workgroup.  Returns false if (lps, wpb) is not instantiated.
 #define MPDATA_WM_LPS(X) X(8) X(16) X(32) X(64)
-// side: a second stream of the plan + fork / join events (null: none) -- the one-tracer kernel of an odd
-// last tracer runs there CONCURRENTLY with the batch kernel (a memory-bound kernel beside a VALU-bound
-// one; one batch wave and two one-tracer waves fit a SIMD's registers together)
-struct MpdataWmSide {
-  void* stream;
-  void* fork;
-  void* join;
-};
 template <typename R, int LPS, int WPB>
-static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags, const MpdataWmSide* side) {
+static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
   // ntracers == 1: wave = tile in dispatch order, u and w streamed; else the per-XCD tracer walk with
   // u, w kept in L2 (see the kernel)
   // MPDATA_WM_NOSTREAM (tests): run the batch form of the kernel on a single tracer as well
@@ -111,13 +103,9 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags, cons
     if (split) b.ntracers = a.ntracers - 1;
     const long long per_xcd = ((long long)(b.ntiles + 7) / 8) * ((b.ntracers + 1) / 2);
     const unsigned blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
-    const bool conc = split && side && side->stream && !(flags & MPDATA_WMF_NOSIDE);
-    hipStream_t s1 = (hipStream_t)stream;
-    if (conc) {   // fork: the side stream starts where the plan's stream stands
-      (void)hipEventRecord((hipEvent_t)side->fork, (hipStream_t)stream);
-      (void)hipStreamWaitEvent((hipStream_t)side->stream, (hipEvent_t)side->fork, 0);
-      s1 = (hipStream_t)side->stream;
-    }
+    // (The one-tracer kernel of the odd tracer BESIDE the batch kernel on a second stream was measured:
+    //  7.394 ms either way at 25 tracers -- two batch waves fill a SIMD's registers, so the second
+    //  kernel's workgroups only get slots in the batch kernel's tail; removed again.)
     hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false, 2>), dim3(blocks), dim3(64 * WPB), 0,
                        (hipStream_t)stream, b);
     if (split) {
@@ -126,21 +114,16 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags, cons
       c.flux = a.flux + (long long)(a.ntracers - 1) * a.flux_tstride;
       c.ntracers = 1;
       const unsigned blocks1 = (unsigned)((c.ntiles + WPB - 1) / WPB);
-      hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, true>), dim3(blocks1), dim3(64 * WPB), 0, s1, c);
-    }
-    if (conc) {   // join
-      (void)hipEventRecord((hipEvent_t)side->join, (hipStream_t)side->stream);
-      (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)side->join, 0);
+      hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, true>), dim3(blocks1), dim3(64 * WPB), 0,
+                         (hipStream_t)stream, c);
     }
   }
 }
-bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags, void* side_stream, void* fork, void* join) {
+bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags) {
   if (wpb != 4) return false;
-  const MpdataWmSide sd{side_stream, fork, join};
-  const MpdataWmSide* side = &sd;
 #define X(LPS_)                             \
   if (lps == LPS_) {                        \
-    launch_wm_t<double, LPS_, 4>(a, stream, flags, side); \
+    launch_wm_t<double, LPS_, 4>(a, stream, flags); \
     return true;                            \
   }
   MPDATA_WM_LPS(X)
@@ -164,10 +147,8 @@ bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream) {
 }
 // fp32 plans: two adjacent instances per lane (8-byte elements = pairs of fp32 values, packed
 // arithmetic); `a` describes the arrays in PAIRS (ncrms / 2 of them)
-bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stream, int flags, void* side_stream, void* fork, void* join) {
+bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stream, int flags) {
   if (wpb != 4) return false;
-  const MpdataWmSide sd{side_stream, fork, join};
-  const MpdataWmSide* side = &sd;
   MpdataWmArgsT<v2::f32x2> a;
   a.f = reinterpret_cast<v2::f32x2*>(a8.f);
   a.u = reinterpret_cast<const v2::f32x2*>(a8.u);
@@ -179,7 +160,7 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   a.u_ref = nullptr; a.w_ref = nullptr; a.ncrms = 0;
 #define X(LPS_)                                \
   if (lps == LPS_) {                           \
-    launch_wm_t<v2::f32x2, LPS_, 4>(a, stream, flags, side); \
+    launch_wm_t<v2::f32x2, LPS_, 4>(a, stream, flags); \
     return true;                               \
   }
   MPDATA_WM_LPS(X)

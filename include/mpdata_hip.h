@@ -248,9 +248,8 @@ int mpdata_get_variant(void);
 int mpdata_set_serpentine(int on);
 /* Test switches of the wave-major launch (bit 0: the batch form of the kernel for one tracer as
  * well, bit 1: one tracer per wave in tracer batches, bit 2: an odd last tracer stays in the
- * two-tracer launch, bit 3: its one-tracer kernel runs behind the batch kernel instead of beside
- * it on a second stream; MPDATA_WM_NOSTREAM / _TPW1 / _NOSPLIT / _NOSIDE in the environment set
- * the initial value); flags < 0 only queries.  Returns the previous value. */
+ * two-tracer launch; MPDATA_WM_NOSTREAM / MPDATA_WM_TPW1 / MPDATA_WM_NOSPLIT in the environment
+ * set the initial value); flags < 0 only queries.  Returns the previous value. */
 int mpdata_set_wm_flags(int flags);
 int mpdata_set_tile(int tile);            /* kernel tiling id; -1 = default */
 int mpdata_set_debug_buffer(void* dev_ptr); /* diagnostic builds only: clock-stamp buffer */

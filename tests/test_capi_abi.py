@@ -106,3 +106,13 @@ def test_default_kernels_do_not_spill():
                     3 if ("wm_kernelIdLi64" in name or "wm_kernelIDv2_fLi64" in name) else 4
                 assert occ >= want, f"{name} occupancy {occ} waves/SIMD"
     assert seen >= 8 + 16   # x-march tilings + wave-major kernels (4 LPS x 2 fetch modes), both variants
+
+
+def test_shipped_library_is_a_production_build(mpdata):
+    """mpdata_version() names every timing-ablation / experiment macro the kernels were compiled with
+    (mpdata_kernels_inst.h: build_flags); some of them produce wrong results by design, and a stray
+    -DMPDWM_ABL_NOCOMPUTE in CXXFLAGS would make a green, fast and wrong bench.  The library the
+    package loads must have been built with none."""
+    v = mpdata.version()
+    assert "exact[]" in v and "fast[]" in v, v
+    assert os.path.basename(mpdata.lib_path()) == "libmpdata_hip.so" or os.environ.get("MPDATA_HIP_LIB")

@@ -124,8 +124,7 @@ def test_batch_form_of_the_kernel_on_single_tracers(M, oracle, monkeypatch, shap
 @pytest.mark.parametrize("shape", [(64, 32, 28), (37, 32, 17), (21, 33, 33), (10, 6, 64), (130, 31, 12), (7, 2, 4)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("ntr", [2, 3])
-@pytest.mark.parametrize("mode", ["exact", "fast", "exact-one-tracer-per-wave", "exact-odd-tracer-in-the-batch",
-                                  "exact-odd-tracer-behind-the-batch"])
+@pytest.mark.parametrize("mode", ["exact", "fast", "exact-one-tracer-per-wave", "exact-odd-tracer-in-the-batch"])
 def test_tracer_batches_two_tracers_per_wave(M, oracle, monkeypatch, shape, ntr, mode):
     """Tracer batches run TWO tracers per wave (u, w and the tracer-independent factors formed once
     for both); the last tracer of an odd count goes through the one-tracer kernel, or -- with
@@ -136,8 +135,6 @@ def test_tracer_batches_two_tracers_per_wave(M, oracle, monkeypatch, shape, ntr,
         M.set_wm_flags(M.WMF_TPW1)
     if mode.endswith("in-the-batch"):
         M.set_wm_flags(M.WMF_NOSPLIT)
-    if mode.endswith("behind-the-batch"):   # (default: beside it, on the plan's side stream)
-        M.set_wm_flags(M.WMF_NOSIDE)
     var = M.VARIANT_FAST if mode == "fast" else M.VARIANT_EXACT
     M.set_variant(var)
     ncrms, nx, nz = shape

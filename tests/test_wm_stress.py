@@ -1,0 +1,113 @@
+"""Regression test of the counted waits of the wave-major kernels (mpdata_kernel_wm_body.h:
+`s_waitcnt vmcnt(N)` with N = the DMA instructions issued AFTER the pair's own -- loads return in
+issue order, stores do not take part in the argument).  Round 2 found the race this replaces
+(stores counted as well: a default-policy store is acknowledged before an older load has landed)
+as sporadic wrong columns in the batch form of the kernel, whose stores use the default policy.
+
+Every form of the kernel is launched many times at full size (ncrms = 65536, nx = 32, nz = 28) on
+the SAME inputs while a second stream keeps HBM saturated with large copies (different memory
+pressure = different load / store completion order); every launch must reproduce the first one BIT
+FOR BIT on the whole array, and the first one is checked against the oracle on sampled instance
+blocks (instances are independent, mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:505-637).
+"""
+import numpy as np
+import pytest
+
+from util import to_host
+
+pytestmark = pytest.mark.gpu
+
+NCRMS, NX, NZ = 65536, 32, 28
+
+
+@pytest.fixture(scope="module")
+def M(mpdata):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    mpdata.set_wm_flags(0)
+    mpdata.set_variant(mpdata.VARIANT_EXACT)
+    yield mpdata
+    mpdata.set_wm_flags(0)
+    mpdata.set_variant(mpdata.VARIANT_EXACT)
+
+
+class HbmPressure:
+    """large device-to-device copies on a second stream, queued ahead of the kernels"""
+
+    def __init__(self, torch, mb=1024, copies=400):
+        self.torch = torch
+        self.s = torch.cuda.Stream()
+        n = mb * 2**20 // 8
+        self.a = torch.empty(n, dtype=torch.float64, device="cuda:0").fill_(1.0)
+        self.b = torch.empty_like(self.a)
+        self.copies = copies
+
+    def start(self):
+        with self.torch.cuda.stream(self.s):
+            for i in range(self.copies):
+                (self.b if i % 2 == 0 else self.a).copy_(self.a if i % 2 == 0 else self.b)
+
+    def stop(self):
+        self.s.synchronize()
+
+
+def _flux_close(flux, ref):
+    nzm = flux.shape[1] - 1
+    return bool(np.all(np.abs(flux[:, :nzm] - ref[:, :nzm]) <= 1e-13 * np.maximum(1.0, np.abs(ref[:, :nzm]))))
+
+
+@pytest.mark.parametrize("form,launches,ntr,ncrms", [("batch-form-one-tracer", 200, 1, NCRMS), ("streaming", 100, 1, NCRMS),
+                                                    ("run_uw", 100, 1, NCRMS), ("two-tracers-per-wave", 40, 3, 16384)])
+def test_every_launch_reproduces_the_first_under_memory_pressure(M, oracle, form, launches, ntr, ncrms):
+    import torch
+    M.set_variant(M.VARIANT_EXACT)
+    M.set_wm_flags(M.WMF_NOSTREAM if form == "batch-form-one-tracer" else 0)
+    sh = M.shapes(ncrms, NX, NZ, 1)
+    d = {k: torch.empty(s, dtype=torch.float64, device="cuda:0") for k, s in sh.items()}
+    for k in d:
+        M.fill_synthetic(d[k], k, 100, oracle.DIST_CONDITIONED)
+    f_in = [d["f"]]
+    for t in range(1, ntr):
+        ft = torch.empty_like(d["f"])
+        M.fill_synthetic(ft, "f", 100 + t, oracle.DIST_CONDITIONED)
+        f_in.append(ft)
+    p = M.Plan(ncrms, NX, NZ, ntr)
+    p.set_stream()
+    p.import_device(None, d["u"], d["w"], d["rho"], d["rhow"], d["adz"], None)
+    fo = [torch.empty_like(d["f"]) for _ in range(ntr)]
+    flo = [torch.empty_like(d["flux"]) for _ in range(ntr)]
+    first_f, first_flux = None, None
+    press = HbmPressure(torch)
+    press.start()
+    bad = []
+    for it in range(launches):
+        for t in range(ntr):
+            p.import_device(f_in[t], flux=d["flux"], first_tracer=t)
+        if form == "run_uw":
+            p.run_uw(d["u"], d["w"])
+        else:
+            p.run()
+        for t in range(ntr):
+            p.export_device(fo[t], flo[t], first_tracer=t)
+        if it == 0:
+            first_f = [x.clone() for x in fo]
+            first_flux = [x.clone() for x in flo]
+        else:
+            for t in range(ntr):
+                if not (torch.equal(fo[t], first_f[t]) and torch.equal(flo[t], first_flux[t])):
+                    bad.append((it, t, int((fo[t] != first_f[t]).sum().item())))
+        if bad:
+            break
+    press.stop()
+    torch.cuda.synchronize()
+    p.close()
+    assert not bad, f"{form}: launch differs from the first one (launch, tracer, elements): {bad[:3]}"
+    # the first launch against the oracle, sampled blocks, every tracer
+    for s0, n in ((0, 40), (ncrms // 2 + 3, 30), (ncrms - 37, 37)):
+        base = oracle.make_inputs(n, NX, NZ, seed=100, dist=oracle.DIST_CONDITIONED, ncrms_global=ncrms, sl0=s0)
+        for t in range(ntr):
+            inp = dict(base)
+            inp["f"] = oracle.fill_array("f", (n, NX + 6, NZ - 1), 100 + t, oracle.DIST_CONDITIONED, ncrms_global=ncrms, sl0=s0)
+            f_ref, flux_ref = oracle.advect(inp)
+            assert np.array_equal(to_host(first_f[t][..., s0:s0 + n]), f_ref), (form, s0, t)
+            assert _flux_close(to_host(first_flux[t][..., s0:s0 + n]), flux_ref), (form, s0, t)

@@ -12,12 +12,13 @@ NCRMS, NX, NZ = 65536, 32, 28
 # (tracer batches); x-march kernel (reference layout)
 # (template arguments: R, LPS, WPB, STREAM, tracers per wave)
 K_WM1, K_WMT, K_XM = "mpdata_advect_wm_kernel<double,32,4,true", "mpdata_advect_wm_kernel<double,32,4,false", "mpdata_advect_xmarch_kernel"
+K_WMX = "mpdata_advect_wm_kernel<double,32,8,true,1,true"   # u, w from the reference layout (mpdata_plan_run_uw)
 
 
 def is_k(kernel, name):
     """kernel-name match on the demangled name, blanks ignored (mangled fragments also accepted)"""
     n = name.replace(" ", "")
-    alt = {K_WM1: "wm_kernelIdLi32ELi4ELb1", K_WMT: "wm_kernelIdLi32ELi4ELb0"}.get(kernel, kernel)
+    alt = {K_WM1: "wm_kernelIdLi32ELi4ELb1", K_WMT: "wm_kernelIdLi32ELi4ELb0", K_WMX: "wm_kernelIdLi32ELi8ELb1ELi1ELb1"}.get(kernel, kernel)
     return kernel in n or alt in n
 
 
@@ -32,26 +33,34 @@ def have(pattern):
     return len(glob.glob(os.path.join(src, pattern), recursive=True)) == 1
 
 
-def counters(passname, kernel):
-    """{counter: mean over the dispatches of `kernel`} (a counter's rows of one dispatch are summed)"""
-    acc, disp = {}, {}
+def full_size_rows(passname, kernel):
+    """rows of the dispatches of `kernel` with the LARGEST grid of the pass: a side block that launches the
+    same kernel on a smaller problem (round 2: the chunked host call) must not enter a per-launch mean"""
+    rows = []
     with open(one(f"{passname}/**/*_counter_collection.csv")) as fh:
-        for row in csv.DictReader(fh):
-            if not is_k(kernel, row["Kernel_Name"]):
-                continue
-            c = row["Counter_Name"]
-            acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
-            disp.setdefault(c, set()).add(row["Dispatch_Id"])
+        rows = [r for r in csv.DictReader(fh) if is_k(kernel, r["Kernel_Name"])]
+    if not rows:
+        raise SystemExit(f"no dispatch of {kernel} in pass {passname}")
+    gmax = max(int(r["Grid_Size"]) for r in rows)
+    return [r for r in rows if int(r["Grid_Size"]) == gmax]
+
+
+def counters(passname, kernel):
+    """{counter: mean over the full-size dispatches of `kernel`} (a counter's rows of one dispatch are summed)"""
+    acc, disp = {}, {}
+    for row in full_size_rows(passname, kernel):
+        c = row["Counter_Name"]
+        acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
+        disp.setdefault(c, set()).add(row["Dispatch_Id"])
     return {c: v / len(disp[c]) for c, v in acc.items()}
 
 
 def durations(passname, kernel):
     """mean End-Start [ns] of the dispatches of `kernel` in a counter pass"""
     seen = {}
-    with open(one(f"{passname}/**/*_counter_collection.csv")) as fh:
-        for row in csv.DictReader(fh):
-            if is_k(kernel, row["Kernel_Name"]) and "End_Timestamp" in row:
-                seen[row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+    for row in full_size_rows(passname, kernel):
+        if "End_Timestamp" in row:
+            seen[row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
     return sum(seen.values()) / len(seen) if seen else None
 
 
@@ -77,6 +86,13 @@ def hbm(fetch_pass, write_pass, kernel):
     return rd, wr
 
 
+def check_traffic(name, traffic_bytes, algorithmic):
+    """HBM traffic below the algorithmic bytes is impossible: it means the wrong dispatches were averaged"""
+    if traffic_bytes < 0.98 * algorithmic:
+        raise SystemExit(f"{name}: measured traffic {traffic_bytes:.4g} B < algorithmic {algorithmic:.4g} B -- "
+                         "the per-launch mean mixes dispatches of different sizes")
+
+
 summary = {"commands": "tools/profile_round.sh: rocprofv3 --kernel-trace --stats and separate --pmc passes "
                        "(FETCH_SIZE | WRITE_SIZE | TCC_* | SQ_*) of bench.py",
            "correction": "FETCH_SIZE KiB x 2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE KiB exact; "
@@ -87,6 +103,7 @@ traffic = {}
 kt = trace("kt", K_WM1, f"{tag}_kernel_stats.csv")
 shutil.copy(one("kt/**/*_domain_stats.csv"), os.path.join(dst, f"{tag}_domain_stats.csv"))
 rd, wr = hbm("fetch", "write", K_WM1)
+check_traffic("t1_wavemajor", rd + wr, alg_bytes(1))
 sq = counters("sq", K_WM1)
 waves = sq["SQ_WAVES"]
 summary["t1_wavemajor"] = {
@@ -112,6 +129,7 @@ if have("t25_fetch/**/*_counter_collection.csv"):
     rd, wr = hbm("t25_fetch", "t25_write", K_WMT)
     rd1, wr1 = hbm("t25_fetch", "t25_write", K_WM1)
     rd, wr = rd + rd1, wr + wr1
+    check_traffic("t25_wavemajor", rd + wr, alg_bytes(25))
     tcc = counters("t25_tcc", K_WMT)
     sq = counters("t25_sq", K_WMT)
     sq1 = counters("t25_sq", K_WM1)
@@ -149,6 +167,7 @@ if have("t25_fetch/**/*_counter_collection.csv"):
 # ---- reference-layout device call (x-march kernel) --------------------------------------------
 if have("ref_fetch/**/*_counter_collection.csv"):
     rd, wr = hbm("ref_fetch", "ref_write", K_XM)
+    check_traffic("t1_reference_layout", rd + wr, alg_bytes(1))
     summary["t1_reference_layout"] = {
         "config": f"ncrms={NCRMS} nx={NX} nz={NZ}, 1 tracer, FAST variant, mpdata_advect_scalar2d_device (x-march kernel)",
         "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg_bytes(1),
@@ -156,6 +175,20 @@ if have("ref_fetch/**/*_counter_collection.csv"):
     for v in ("fast", "exact"):
         traffic[f"{v}_ncrms{NCRMS}_nx{NX}_nz{NZ}_t1"] = {"hbm_bytes_per_launch": rd + wr,
                                                          "source": f"profiles/{tag}_pmc_summary.json t1_reference_layout"}
+
+# ---- mpdata_plan_run_uw: f in the plan layout, u and w fetched from the reference layout ----------
+if have("uw_fetch/**/*_counter_collection.csv"):
+    ktu = trace("uw_kt", K_WMX, f"{tag}_uw_kernel_stats.csv")
+    rd, wr = hbm("uw_fetch", "uw_write", K_WMX)
+    check_traffic("t1_run_uw", rd + wr, alg_bytes(1))
+    summary["t1_run_uw"] = {
+        "config": f"ncrms={NCRMS} nx={NX} nz={NZ}, 1 tracer, FAST variant, mpdata_plan_run_uw (u, w reference layout, f plan layout)",
+        "kernel_trace": ktu, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+        "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg_bytes(1),
+        "ratio_traffic_over_algorithmic": (rd + wr) / alg_bytes(1),
+        "frac_of_8TBs": alg_bytes(1) / ktu["avg_ns"] / 8000.0 if ktu else None}
+    traffic[f"fast_ncrms{NCRMS}_nx{NX}_nz{NZ}_t1_uw"] = {"hbm_bytes_per_launch": rd + wr,
+                                                        "source": f"profiles/{tag}_pmc_summary.json t1_run_uw"}
 
 with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
@@ -182,3 +215,29 @@ if have("bwk_kt/**/*_kernel_stats.csv"):
     with open(os.path.join(dst, f"{tag}_bwk_summary.json"), "w") as fh:
         json.dump(bsum, fh, indent=1)
     print(json.dumps(bsum, indent=1))
+
+# ---- third kernel: high-order flux nest on the 32 x mesh (tools/nlk_bench.py: local, then random connectivity)
+if have("nlk_kt/**/*_kernel_stats.csv"):
+    KERNEL = "nlk_kernel"
+    shutil.copy(one("nlk_kt/**/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_nlk_kernel_stats.csv"))
+    per = {}
+    for which in ("nlk_fetch", "nlk_write"):
+        for row in full_size_rows(which, KERNEL):
+            per.setdefault(row["Dispatch_Id"], {}).setdefault(row["Counter_Name"], 0.0)
+            per[row["Dispatch_Id"]][row["Counter_Name"]] += float(row["Counter_Value"])
+    # dispatch order = tools/nlk_bench.py's order: first half local connectivity, second half random
+    def mean(ids, name, scale):
+        v = [per[i][name] for i in ids if name in per[i]]
+        return sum(v) / len(v) * scale if v else None
+    ids = sorted(per, key=int)
+    fe = [i for i in ids if "FETCH_SIZE" in per[i]]; wr_ = [i for i in ids if "WRITE_SIZE" in per[i]]
+    half_f, half_w = len(fe) // 2, len(wr_) // 2
+    nsum = {"kernel": "nlk_kernel, nEdges=819200 nCells=89600 nVertLevels=100 nAdv=10",
+            "commands": "tools/profile_round.sh (python3 tools/nlk_bench.py: N launches local connectivity, then N random)",
+            "local_connectivity": {"hbm_read_bytes_per_launch": mean(fe[:half_f], "FETCH_SIZE", 2048),
+                                   "hbm_write_bytes_per_launch": mean(wr_[:half_w], "WRITE_SIZE", 1024)},
+            "random_connectivity": {"hbm_read_bytes_per_launch": mean(fe[half_f:], "FETCH_SIZE", 2048),
+                                    "hbm_write_bytes_per_launch": mean(wr_[half_w:], "WRITE_SIZE", 1024)}}
+    with open(os.path.join(dst, f"{tag}_nlk_summary.json"), "w") as fh:
+        json.dump(nsum, fh, indent=1)
+    print(json.dumps(nsum, indent=1))
