@@ -432,6 +432,7 @@ def bench_plan(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, s
     if shared_uw:
         plan = M.Plan(n_loc, nx, nz, nset * ntr, dtype=np_dtype)
         plan.set_stream()
+        plan.set_timing(False)   # (timed_loop brackets the K launches with ONE event pair)
         plan.import_device(None, shared["u"], shared["w"], shared["rho"], shared["rhow"], shared["adz"], None)
         for t in range(nset * ntr):     # per-tracer / per-set seeds: distinct data, same law
             M.fill_synthetic(ftmp, "f", 100 + t, dist_law, ncrms_global=n_glob, sl0=sl0)
@@ -444,6 +445,7 @@ def bench_plan(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, s
         for sset in range(nset):
             pl = M.Plan(n_loc, nx, nz, ntr, dtype=np_dtype)
             pl.set_stream()
+            pl.set_timing(False)   # (timed_loop brackets the K launches with ONE event pair)
             for k in tmp:
                 M.fill_synthetic(tmp[k], k, 100 + 7919 * (sset + 1), dist_law, ncrms_global=n_glob, sl0=sl0)
             if sset == 0:   # layout-entry cost, measured on its own (no fill inside): u + w, then one tracer of f
@@ -490,6 +492,7 @@ def bench_fresh_uw(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glo
     for s_ in range(nsets):
         pl = M.Plan(n_loc, nx, nz, 1, dtype=np_dtype)
         pl.set_stream()
+        pl.set_timing(False)
         u = torch.empty_like(shared["u"]); w = torch.empty_like(shared["w"])
         M.fill_synthetic(u, "u", 500 + 31 * s_, dist_law, ncrms_global=n_glob, sl0=sl0)
         M.fill_synthetic(w, "w", 500 + 31 * s_, dist_law, ncrms_global=n_glob, sl0=sl0)

@@ -73,6 +73,8 @@ def lib():
         L.mpdata_plan_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         L.mpdata_plan_run_tracers.restype = ci
         L.mpdata_plan_run_tracers.argtypes = [vp, ci, ci]
+        L.mpdata_plan_set_timing.restype = ci
+        L.mpdata_plan_set_timing.argtypes = [vp, ci]
         L.mpdata_plan_run_uw.restype = ci
         L.mpdata_plan_run_uw.argtypes = [vp, ci, ci, vp, vp]
         L.mpdata_plan_import_device.restype = ci
@@ -484,6 +486,10 @@ class Plan:
     def set_stream(self, stream=None):
         """Run on a torch stream (default: torch's current stream) from now on."""
         _check(lib().mpdata_plan_set_stream(self._p, _stream_handle(stream)))
+
+    def set_timing(self, on):
+        """the plan's own event pair around every run (last_kernel_ms) on / off (mpdata_plan_set_timing)"""
+        _check(lib().mpdata_plan_set_timing(self._p, int(bool(on))))
 
     def last_kernel_ms(self):
         ms = ctypes.c_double()

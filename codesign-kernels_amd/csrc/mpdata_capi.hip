@@ -385,6 +385,7 @@ struct mpdata_plan {
   bool own_stream;
   hipEvent_t ev0, ev1;
   bool uploaded, ran;
+  bool timing;     // record the event pair around every run (mpdata_plan_last_kernel_ms); mpdata_plan_set_timing
   unsigned runs;   // launches so far (serpentine tile order)
   mpdata_multi* multi;  // != null: a multi-GPU plan (mpdata_multi.hip); nothing else above is used
 };
@@ -624,6 +625,7 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   if (e == hipSuccess) p->own_stream = true;
   if (e == hipSuccess) e = hipEventCreate(&p->ev0);
   if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+  p->timing = true;
   if (e != hipSuccess) {
     mpdata_plan_destroy(p);
     return hip_err(e, "mpdata_plan_create");
@@ -765,11 +767,11 @@ int mpdata_plan_run_tracers(mpdata_plan* p, int first, int count) {
   }
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run before mpdata_plan_upload");
   DevGuard g(p->device);
-  HIP_TRY(hipEventRecord(p->ev0, p->stream));
+  if (p->timing) HIP_TRY(hipEventRecord(p->ev0, p->stream));
   rc = plan_launch(p, first, count);
   if (rc) return rc;
-  HIP_TRY(hipEventRecord(p->ev1, p->stream));
-  p->ran = true;
+  if (p->timing) HIP_TRY(hipEventRecord(p->ev1, p->stream));
+  p->ran = p->timing;
   return 0;
 }
 int mpdata_plan_run(mpdata_plan* p) {
@@ -788,7 +790,7 @@ int mpdata_plan_run_uw(mpdata_plan* p, int first, int count, const void* u, cons
   if (rc) return rc;
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run_uw before upload / import");
   DevGuard g(p->device);
-  HIP_TRY(hipEventRecord(p->ev0, p->stream));
+  if (p->timing) HIP_TRY(hipEventRecord(p->ev0, p->stream));
   // one fp64 tracer of a wave-major plan: the kernel fetches u, w from the caller's arrays itself
   // (16-byte row pieces: even ncrms, 16-byte aligned bases; 32-bit offsets: arrays below 4 GiB);
   // MPDATA_RUN_UW=import forces the conversion path (tests, A/B)
@@ -804,8 +806,8 @@ int mpdata_plan_run_uw(mpdata_plan* p, int first, int count, const void* u, cons
     rc = plan_launch(p, first, count);
   }
   if (rc) return rc;
-  HIP_TRY(hipEventRecord(p->ev1, p->stream));
-  p->ran = true;
+  if (p->timing) HIP_TRY(hipEventRecord(p->ev1, p->stream));
+  p->ran = p->timing;
   return 0;
 }
 
@@ -855,6 +857,18 @@ int mpdata_plan_set_stream(mpdata_plan* p, void* stream) {
   if (p->own_stream) (void)hipStreamDestroy(p->stream);
   p->stream = (hipStream_t)stream;
   p->own_stream = false;
+  return 0;
+}
+// The event pair a plan records around every run costs two marker packets between consecutive
+// launches of a stream (about 1.5 % of a 0.4-ms kernel): a caller that times a whole loop itself
+// switches it off (mpdata_plan_last_kernel_ms then reports MPDATA_ESTATE).
+int mpdata_plan_set_timing(mpdata_plan* p, int on) {
+  if (!p) return set_err(MPDATA_EINVAL, "null plan");
+  if (p->multi) {
+    for (int g = 0; g < mpdata_multi_ngpus(p->multi); ++g) mpdata_multi_sub(p->multi, g)->timing = on != 0;
+    return 0;
+  }
+  p->timing = on != 0;
   return 0;
 }
 int mpdata_plan_layout(const mpdata_plan* p) { return p ? p->layout : MPDATA_EINVAL; }

@@ -132,16 +132,26 @@ __global__ void __launch_bounds__(256) wm_convert_cols_kernel(const MpdataLayout
       }
     }
   }
+  // running pointers: every column advances them by a constant (no 64-bit multiply per element and column)
   const long long rcol = j.ncrms * j.ref_colmul;   // reference-side elements between columns
+  R* rp[NPT];
+  R* pp[NPT];
+  long long pstep[NPT];
+#pragma unroll
+  for (int e = 0; e < NPT; ++e) {
+    rp[e] = ref + ro[e];
+    pstep[e] = pmain[e] ? j.main_e : rem_e;
+    pp[e] = prv + po[e] + (long long)j.prv_col0 * pstep[e];
+  }
   R v[NPT];
-  auto fetch = [&](const int cs) {
+  auto fetch = [&]() {   // the column the pointers stand on; then on to the next
 #pragma unroll
     for (int e = 0; e < NPT; ++e) {
-      if (TO_PRIVATE) { if (rl[e] >= 0) v[e] = ref[ro[e] + rcol * cs]; }
-      else if (pl[e] >= 0) v[e] = prv[po[e] + (long long)(cs + j.prv_col0) * (pmain[e] ? j.main_e : rem_e)];
+      if (TO_PRIVATE) { if (rl[e] >= 0) v[e] = *rp[e]; }
+      else if (pl[e] >= 0) v[e] = *pp[e];
     }
   };
-  fetch(0);
+  fetch();
   for (int cs = 0; cs < j.ncols; ++cs) {
     R* tb = tile + (cs & 1) * tsz;
 #pragma unroll
@@ -150,11 +160,16 @@ __global__ void __launch_bounds__(256) wm_convert_cols_kernel(const MpdataLayout
       if (l >= 0) tb[l] = v[e];
     }
     __syncthreads();   // (two buffers: the previous column's readers are past the barrier of this one's predecessor)
-    if (cs + 1 < j.ncols) fetch(cs + 1);
+    // the source pointers move on and the next column is fetched while this one goes out of the tile
 #pragma unroll
     for (int e = 0; e < NPT; ++e) {
-      if (TO_PRIVATE) { if (pl[e] >= 0) prv[po[e] + (long long)(cs + j.prv_col0) * (pmain[e] ? j.main_e : rem_e)] = tb[pl[e]]; }
-      else if (rl[e] >= 0) ref[ro[e] + rcol * cs] = tb[rl[e]];
+      if (TO_PRIVATE) rp[e] += rcol; else pp[e] += pstep[e];
+    }
+    if (cs + 1 < j.ncols) fetch();
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) {
+      if (TO_PRIVATE) { if (pl[e] >= 0) *pp[e] = tb[pl[e]]; pp[e] += pstep[e]; }
+      else { if (rl[e] >= 0) *rp[e] = tb[rl[e]]; rp[e] += rcol; }
     }
   }
 }

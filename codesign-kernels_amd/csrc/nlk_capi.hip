@@ -12,10 +12,10 @@
 #include "nlk_args.h"
 
 namespace nlk_exact {
-void launch(const NlkArgs& g, void* stream);
+void launch(const NlkArgs& g, void* stream, int force);
 }
 namespace nlk_fast {
-void launch(const NlkArgs& g, void* stream);
+void launch(const NlkArgs& g, void* stream, int force);
 }
 
 namespace {
@@ -29,6 +29,14 @@ int set_err(int code, const char* fmt, ...) {
   va_end(ap);
   g_err = buf;
   return code;
+}
+int g_pipe = -2;   // -2: read NLK_PIPE on first use; -1 automatic, 0 one edge per wave, 1 pipelined persistent waves
+int pipe_mode() {
+  if (g_pipe == -2) {
+    const char* f = getenv("NLK_PIPE");
+    g_pipe = f ? (atoi(f) != 0) : -1;
+  }
+  return g_pipe;
 }
 int variant() {
   if (g_variant < 0) {
@@ -72,12 +80,12 @@ int nlk_high_order_flux_device(int nEdges, int nCells, int nVertLevels, int nvld
     nlk_fast::launch(fill(nEdges, nCells, nVertLevels, nvldim, nAdv, nAdvCellsForEdge,
                                              advCellsForEdge, minLevelCell, maxLevelCell, tracerCur,
                                              normalThicknessFlux, advMaskHighOrder, advCoefs, advCoefs3rd,
-                                             coef3rdOrder, highOrderFlx), stream);
+                                             coef3rdOrder, highOrderFlx), stream, pipe_mode());
   else
     nlk_exact::launch(fill(nEdges, nCells, nVertLevels, nvldim, nAdv, nAdvCellsForEdge,
                                                advCellsForEdge, minLevelCell, maxLevelCell, tracerCur,
                                                normalThicknessFlux, advMaskHighOrder, advCoefs, advCoefs3rd,
-                                               coef3rdOrder, highOrderFlx), stream);
+                                               coef3rdOrder, highOrderFlx), stream, pipe_mode());
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_err((int)e, "nlk kernel launch: %s", hipGetErrorString(e));
   return 0;
@@ -123,6 +131,11 @@ int nlk_set_variant(int v) {
   return prev;
 }
 int nlk_get_variant(void) { return variant(); }
+int nlk_set_kernel(int mode) {
+  const int prev = pipe_mode();
+  if (mode >= -1 && mode <= 1) g_pipe = mode;
+  return prev;
+}
 int64_t nlk_algorithmic_bytes(int nEdges, int nCells, int nVertLevels, int nvldim, int nAdv) {
   (void)nvldim;
   return (int64_t)8 * nVertLevels * ((int64_t)nCells + 3ll * nEdges) + (int64_t)nEdges * (4 + (int64_t)nAdv * 20) +

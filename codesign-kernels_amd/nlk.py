@@ -35,6 +35,8 @@ def lib():
         L.nlk_high_order_flux.argtypes = [ci] * 5 + [vp] * 9 + [ctypes.c_double, vp]
         L.nlk_set_variant.restype = ci
         L.nlk_set_variant.argtypes = [ci]
+        L.nlk_set_kernel.restype = ci
+        L.nlk_set_kernel.argtypes = [ci]
         L.nlk_algorithmic_bytes.restype = ctypes.c_int64
         L.nlk_algorithmic_bytes.argtypes = [ci] * 5
         L.nlk_last_error.restype = ctypes.c_char_p
@@ -49,6 +51,11 @@ def _check(rc):
 
 def set_variant(v):
     return lib().nlk_set_variant(int(v))
+
+
+def set_kernel(mode):
+    """-1 automatic, 0 one edge per wave, 1 persistent pipelined waves (nlk_set_kernel); returns the previous setting"""
+    return lib().nlk_set_kernel(int(mode))
 
 
 def algorithmic_bytes(nEdges, nCells, nVertLevels, nvldim, nAdv):

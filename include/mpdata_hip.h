@@ -119,6 +119,10 @@ int mpdata_plan_run_uw(mpdata_plan* plan, int first_tracer, int ntracers, const 
 int mpdata_plan_sync(mpdata_plan* plan);           /* the `!$acc wait` (:237) */
 int mpdata_plan_download(mpdata_plan* plan, double* f, double* flux);  /* host arrays */
 int mpdata_plan_last_kernel_ms(mpdata_plan* plan, double* ms); /* hipEvent time of the last run */
+/* The event pair behind mpdata_plan_last_kernel_ms is recorded around EVERY run (two marker packets
+ * between consecutive launches of a stream, about 1.5 % of a 0.4-ms kernel).  on = 0 switches it
+ * off for callers that time a whole loop themselves; last_kernel_ms then returns MPDATA_ESTATE. */
+int mpdata_plan_set_timing(mpdata_plan* plan, int on);
 int mpdata_plan_destroy(mpdata_plan* plan);
 /* Device-side exchange with a plan: reference-layout DEVICE arrays of the plan's precision on
  * the plan's device, asynchronous on the plan's stream.  Import: NULL pointers are skipped

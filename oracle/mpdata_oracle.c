@@ -277,17 +277,23 @@ int SYM(mpdata_oracle_advect)(int64_t ncrms, int nx, int nz, real *f, const real
       dims_t dl = d;
       scratch_t sl_;
       int64_t c;
+      int mine_ok;
       dl.sn = chunk;
-      if (scratch_alloc(&sl_, dl) != 0) {
+      mine_ok = scratch_alloc(&sl_, dl) == 0;
+      if (!mine_ok) {
 #ifdef _OPENMP
 #pragma omp atomic write
 #endif
         failed = 1;
-      } else {
+      }
+      /* EVERY thread of the team meets the worksharing loop (a thread that skipped it would leave the
+         others at its implicit barrier: non-conforming); one without scratch takes no chunk's body, and
+         the call fails as a whole */
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif
-        for (c = 0; c < nchunks; c++) {
+      for (c = 0; c < nchunks; c++) {
+        if (mine_ok) {
           int64_t s0 = c * chunk, s1 = s0 + chunk < ncrms ? s0 + chunk : ncrms;
           dl.so = s0;
           advect_range(dl, s0, s1, f, u, w, rho, rhow, adz, flux, sl_, 8);

@@ -103,6 +103,7 @@ def K():
     import codesign_kernels_amd.nlk as nlk_hip
     yield nlk_hip
     nlk_hip.set_variant(nlk_hip.VARIANT_EXACT)
+    nlk_hip.set_kernel(-1)
 
 
 @pytest.mark.gpu
@@ -117,11 +118,14 @@ def test_hip_exact_reproduces_reference_golden_bitwise(K):
                                    (500, 70, 100, 10, 104), (9, 300, 200, 12, 200), (64, 5, 3, 2, 8)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("variant", [0, 1], ids=["exact", "fast"])
-def test_hip_matches_oracle(K, N, shape, variant):
+@pytest.mark.parametrize("kernel", [0, 1], ids=["edge-per-wave", "pipelined"])
+def test_hip_matches_oracle(K, N, shape, variant, kernel):
     """The shipped namelist size; level counts around the wave width; padded leading dimension
     (nvldim > nVertLevels: padding rows stay untouched); ragged nAdvCellsForEdge, minLevelCell > 1,
-    masked levels, negative zero fluxes."""
+    masked levels, negative zero fluxes.  Both kernel forms (nlk_set_kernel): one edge per wave, and the
+    persistent waves that pipeline the cell lists / level ranges of their next edges (large meshes)."""
     K.set_variant(variant)
+    K.set_kernel(kernel)
     nE, nC, nV, nA, nvldim = shape
     inp = N.make_inputs(nE, nC, nV, nA, seed=sum(shape[:4]), nvldim=nvldim, ragged=True)
     inp["normalThicknessFlux"][0, :] = -0.0          # sign(1.0, -0.0) = -1 (nested.F90:128)
@@ -133,6 +137,17 @@ def test_hip_matches_oracle(K, N, shape, variant):
     else:
         rel = np.abs(out[:nV] - ref[:nV]) / np.maximum(np.abs(ref[:nV]), 1e-300)
         assert np.all((rel <= 1e-10) | (np.abs(out[:nV] - ref[:nV]) <= 1e-12))   # errTol, nested_vars.F90:36
+    K.set_kernel(-1)
+
+
+@pytest.mark.gpu
+def test_hip_pipelined_kernel_many_edges_per_wave(K, N):
+    """A mesh with more edges than the chip has wave slots (the automatic choice takes the pipelined
+    kernel: every wave walks a range of edges), ragged cell counts, EXACT: bitwise vs the oracle."""
+    K.set_variant(K.VARIANT_EXACT)
+    K.set_kernel(-1)
+    inp = N.make_inputs(40000, 900, 40, 10, seed=77, ragged=True)
+    assert np.array_equal(run_hip(K, inp)[:40], N.high_order_flux(inp)[:40])
 
 
 @pytest.mark.gpu

@@ -55,6 +55,7 @@ for s in range(a.sets):
     M.fill_synthetic(ftmp, "f", 100 + s, 1)
     p = M.Plan(ncrms, nx, nz, 1)
     p.set_stream()
+    p.set_timing(False)
     p.import_device(ftmp, u, w, small["rho"], small["rhow"], small["adz"], small["flux"])
     sets.append((p, u, w))
 torch.cuda.synchronize()
