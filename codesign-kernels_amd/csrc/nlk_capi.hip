@@ -12,10 +12,10 @@
 #include "nlk_args.h"
 
 namespace nlk_exact {
-void launch(const NlkArgs& g, void* stream, int force);
+void launch(const NlkArgs& g, void* stream, int mode);
 }
 namespace nlk_fast {
-void launch(const NlkArgs& g, void* stream, int force);
+void launch(const NlkArgs& g, void* stream, int mode);
 }
 
 namespace {
@@ -30,13 +30,13 @@ int set_err(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
-int g_pipe = -2;   // -2: read NLK_PIPE on first use; -1 automatic, 0 one edge per wave, 1 pipelined persistent waves
-int pipe_mode() {
-  if (g_pipe == -2) {
-    const char* f = getenv("NLK_PIPE");
-    g_pipe = f ? (atoi(f) != 0) : -1;
+int g_kernel = -2;   // -2: read NLK_KERNEL on first use; -1 automatic, 0 one level per lane, 1 two levels per lane
+int kernel_mode() {
+  if (g_kernel == -2) {
+    const char* f = getenv("NLK_KERNEL");
+    g_kernel = f ? (atoi(f) != 0) : -1;
   }
-  return g_pipe;
+  return g_kernel;
 }
 int variant() {
   if (g_variant < 0) {
@@ -80,12 +80,12 @@ int nlk_high_order_flux_device(int nEdges, int nCells, int nVertLevels, int nvld
     nlk_fast::launch(fill(nEdges, nCells, nVertLevels, nvldim, nAdv, nAdvCellsForEdge,
                                              advCellsForEdge, minLevelCell, maxLevelCell, tracerCur,
                                              normalThicknessFlux, advMaskHighOrder, advCoefs, advCoefs3rd,
-                                             coef3rdOrder, highOrderFlx), stream, pipe_mode());
+                                             coef3rdOrder, highOrderFlx), stream, kernel_mode());
   else
     nlk_exact::launch(fill(nEdges, nCells, nVertLevels, nvldim, nAdv, nAdvCellsForEdge,
                                                advCellsForEdge, minLevelCell, maxLevelCell, tracerCur,
                                                normalThicknessFlux, advMaskHighOrder, advCoefs, advCoefs3rd,
-                                               coef3rdOrder, highOrderFlx), stream, pipe_mode());
+                                               coef3rdOrder, highOrderFlx), stream, kernel_mode());
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_err((int)e, "nlk kernel launch: %s", hipGetErrorString(e));
   return 0;
@@ -132,8 +132,8 @@ int nlk_set_variant(int v) {
 }
 int nlk_get_variant(void) { return variant(); }
 int nlk_set_kernel(int mode) {
-  const int prev = pipe_mode();
-  if (mode >= -1 && mode <= 1) g_pipe = mode;
+  const int prev = kernel_mode();
+  if (mode >= -1 && mode <= 1) g_kernel = mode;
   return prev;
 }
 int64_t nlk_algorithmic_bytes(int nEdges, int nCells, int nVertLevels, int nvldim, int nAdv) {

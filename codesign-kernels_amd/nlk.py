@@ -54,7 +54,7 @@ def set_variant(v):
 
 
 def set_kernel(mode):
-    """-1 automatic, 0 one edge per wave, 1 persistent pipelined waves (nlk_set_kernel); returns the previous setting"""
+    """-1 automatic, 0 one level per lane, 1 two levels per lane (nlk_set_kernel); returns the previous setting"""
     return lib().nlk_set_kernel(int(mode))
 
 

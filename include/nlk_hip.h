@@ -56,9 +56,10 @@ int nlk_high_order_flux(int nEdges, int nCells, int nVertLevels, int nvldim, int
                         double* highOrderFlx);
 int nlk_set_variant(int variant); /* returns the previous one; default: NLK_VARIANT env or exact */
 int nlk_get_variant(void);
-/* kernel form: -1 automatic (default; NLK_PIPE=0 / 1 in the environment presets it), 0 one edge per wave,
- * 1 persistent waves with a software pipeline over their edges (the form for meshes with several edges
- * per wave slot of the chip).  Same results.  Returns the previous setting. */
+/* kernel form: -1 automatic (default; NLK_KERNEL=0 / 1 in the environment presets it), 0 one level per
+ * lane (8-byte accesses), 1 two levels per lane (16-byte accesses: half the vector-memory instructions;
+ * needs an even nvldim and 16-byte aligned arrays, else form 0 is taken).  Same results.  Returns the
+ * previous setting. */
 int nlk_set_kernel(int mode);
 /* minimal HBM traffic of one call: every input array read once, highOrderFlx written once
  * (the gather re-reads of tracerCur hit in cache: 10 x 100 x 8 B per edge from 2.2 MB) */

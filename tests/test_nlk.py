@@ -118,12 +118,13 @@ def test_hip_exact_reproduces_reference_golden_bitwise(K):
                                    (500, 70, 100, 10, 104), (9, 300, 200, 12, 200), (64, 5, 3, 2, 8)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("variant", [0, 1], ids=["exact", "fast"])
-@pytest.mark.parametrize("kernel", [0, 1], ids=["edge-per-wave", "pipelined"])
+@pytest.mark.parametrize("kernel", [0, 1], ids=["one-level-per-lane", "two-levels-per-lane"])
 def test_hip_matches_oracle(K, N, shape, variant, kernel):
     """The shipped namelist size; level counts around the wave width; padded leading dimension
     (nvldim > nVertLevels: padding rows stay untouched); ragged nAdvCellsForEdge, minLevelCell > 1,
-    masked levels, negative zero fluxes.  Both kernel forms (nlk_set_kernel): one edge per wave, and the
-    persistent waves that pipeline the cell lists / level ranges of their next edges (large meshes)."""
+    masked levels (the kernel takes them from the range check of a per-cell buffer descriptor and adds
+    exact zeros instead of skipping), negative zero fluxes.  Both kernel forms (nlk_set_kernel; two levels
+    per lane needs an even nvldim, else the library takes the other one)."""
     K.set_variant(variant)
     K.set_kernel(kernel)
     nE, nC, nV, nA, nvldim = shape
@@ -137,17 +138,19 @@ def test_hip_matches_oracle(K, N, shape, variant, kernel):
     else:
         rel = np.abs(out[:nV] - ref[:nV]) / np.maximum(np.abs(ref[:nV]), 1e-300)
         assert np.all((rel <= 1e-10) | (np.abs(out[:nV] - ref[:nV]) <= 1e-12))   # errTol, nested_vars.F90:36
-    K.set_kernel(-1)
 
 
 @pytest.mark.gpu
-def test_hip_pipelined_kernel_many_edges_per_wave(K, N):
-    """A mesh with more edges than the chip has wave slots (the automatic choice takes the pipelined
-    kernel: every wave walks a range of edges), ragged cell counts, EXACT: bitwise vs the oracle."""
+def test_hip_larger_mesh_ragged_bitwise(K, N):
+    """40000 edges, ragged cell counts and level ranges (minLevelCell > 1 on some cells), EXACT: bitwise vs the
+    oracle; every kernel choice."""
     K.set_variant(K.VARIANT_EXACT)
-    K.set_kernel(-1)
     inp = N.make_inputs(40000, 900, 40, 10, seed=77, ragged=True)
-    assert np.array_equal(run_hip(K, inp)[:40], N.high_order_flux(inp)[:40])
+    ref = N.high_order_flux(inp)[:40]
+    for mode in (1, -1, 0):
+        K.set_kernel(mode)
+        assert np.array_equal(run_hip(K, inp)[:40], ref), mode
+    K.set_kernel(-1)
 
 
 @pytest.mark.gpu
