@@ -1,0 +1,31 @@
+#!/bin/bash
+# The records of a round, on the GPU box:  bash tools/record_round.sh r03
+#   gpurun_out/<tag>_final/bench_driver.json   bench.py with the driver's arguments (--steps 20 --warmup 5)
+#   gpurun_out/<tag>_final/bench_default.json  bench.py with its defaults (100 + 100 launches)
+#   gpurun_out/<tag>_final/fortran_driver.txt  the Fortran driver: host mode (1 tracer), device mode (25 tracers),
+#                                              ngpus = 1 through the multi-GPU path, 2 shards on one device
+#   gpurun_out/prof_<tag>/                      tools/profile_round.sh (rocprofv3 kernel trace + PMC passes)
+# then here: python tools/pmc_summary.py <tag>; copy the records into profiles/.
+TAG=${1:-r03}
+OUT=gpurun_out/${TAG}_final
+mkdir -p $OUT
+timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; echo "bench driver rc=$?"
+timeout -k 10 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default rc=$?"
+F=codesign-kernels_amd/fortran/advect
+{
+  echo "== host mode, 1 tracer, FAST:  $F 65536 32 28 1 1 - - 1 1 host"
+  $F 65536 32 28 1 1 - - 1 1 host
+  echo "== device mode, 1 tracer, FAST:  $F 65536 32 28 1 1 - - 1 1 device"
+  $F 65536 32 28 1 1 - - 1 1 device
+  echo "== device mode, 25 tracers (BASELINE configs[3]), FAST:  $F 65536 32 28 1 1 - - 25 1 device"
+  $F 65536 32 28 1 1 - - 25 1 device
+  echo "== ngpus = 2 on ONE device (MPDATA_MULTI_DEVICES=0,0: peer-copy transport), device mode, 25 tracers, ncrms = 131072"
+  MPDATA_MULTI_DEVICES=0,0 $F 131072 32 28 1 1 - - 25 2 device
+  echo "== ngpus = 2 on ONE device, host mode (direct transport), 2 tracers, ncrms = 65536"
+  MPDATA_MULTI_DEVICES=0,0 $F 65536 32 28 1 1 - - 2 2 host
+  echo "== namelist: configs[3] through a namelist file"
+  printf "&advect_nml ncrms=65536, nx=32, nz=28, dist=1, variant=1, ntracers=25, ngpus=1, mode='device' /\n" > $OUT/case.nml
+  $F $OUT/case.nml
+} > $OUT/fortran_driver.txt 2>&1
+echo "fortran rc=$?"
+timeout -k 10 700 bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1; echo "profile rc=$?"
