@@ -663,7 +663,7 @@ def main():
         M.set_serpentine(1)
         ssteps = min(steps, 40)
         dt6, kms6, info6 = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, 1, ssteps,
-                                      min(warmup, SIDE_WARMUP), args.dist, npdt, tdt, 0.3 * mem_frac, shared_uw=True)
+                                      SIDE_WARMUP, args.dist, npdt, tdt, 0.3 * mem_frac, shared_uw=True)
         M.set_serpentine(serp)
         if rank == 0:
             result["consecutive_tracers_shared_uw"] = {
@@ -678,7 +678,7 @@ def main():
     if not args.no_fresh_uw and ntr == 1 and not f32:
         fsteps = min(steps, 40)
         dt7, kms7, nfs = bench_fresh_uw(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, fsteps,
-                                        min(warmup, SIDE_WARMUP), args.dist, npdt, tdt)
+                                        SIDE_WARMUP, args.dist, npdt, tdt)
         if rank == 0:
             result["step_with_fresh_uw"] = {
                 "workload": f"mpdata_plan_run_uw: f resident in the plan layout, u and w handed over as reference-layout "

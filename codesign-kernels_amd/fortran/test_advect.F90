@@ -95,8 +95,15 @@ program test_advect
     write(*,*) 'cell updates per call: ', nslices*int(nx,8)*int(nzm,8)*int(ntracers,8)
     write(*,*) 'checksum f   : ', d_sumf
     write(*,*) 'checksum flux: ', d_sumflux
-    stop
+  else
+    call run_host_mode()
   end if
+
+contains
+
+  !> the reference's own situation: global arrays on the host (init on the host, `update device`, kernels,
+  !! `update host`; :48-58, :105-110, :237-242)
+  subroutine run_host_mode()
   allocate(f(nslices, -2:nx+3, 1, nzm, ntracers), u(nslices, -1:nx+3, 1, nzm), w(nslices, -1:nx+2, 1, nz))
   allocate(rho(nslices, nzm), rhow(nslices, nz), flux(nslices, nz, ntracers))
   write(*,*) 'ncrms, nx, nz, ntracers, ngpus: ', nslices, nx, nz, ntracers, ngpus
@@ -137,8 +144,7 @@ program test_advect
   write(*,*) 'cell updates per call: ', nslices*int(nx,8)*int(nzm,8)*int(ntracers,8)
   write(*,*) 'checksum f   : ', sum(f)
   write(*,*) 'checksum flux: ', sum(flux(:,1:nzm,:))
-
-contains
+  end subroutine run_host_mode
 
   !> the namelist form of the command line; names as in BASELINE.json / the C-ABI.  Values not
   !! named in the file keep the defaults passed in.
