@@ -1,4 +1,4 @@
-"""The recorded bench line (profiles/r02_bench.json, written by bench.py on an MI355X) carries what
+"""The recorded bench line (profiles/r03_bench.json, written by bench.py on an MI355X) carries what
 the measurement contract asks for: the headline keys, the `roofline` object of the dominant kernel
 and the `cpu_baseline` object, with consistent arithmetic.  CPU-only: it reads the committed record."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _record():
-    with open(os.path.join(ROOT, "profiles", "r02_bench.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r03_bench.json")) as fh:
         return json.loads(fh.read().strip().splitlines()[-1])
 
 
@@ -22,6 +22,8 @@ def test_headline_keys_and_workload():
     assert d["dtype"] == "f64" and d["data"] == "synthetic"
     c = d["config"]
     assert "configs[2]" in c["workload"] and (c["ncrms_per_gpu"], c["nx"], c["nz"], c["ntracers"]) == (65536, 32, 28, 1)
+    # the headline is a COLD measurement and says so: own u, w per timed step, no serpentine tile order
+    assert c["uw_shared_across_steps"] is False and c["serpentine"] is False and c["steps_per_field_set"] >= 1
     # whole-job throughput = cells per step / seconds per step
     cells = c["ncrms_global"] * c["nx"] * (c["nz"] - 1) * c["ntracers"]
     assert abs(d["value"] - cells / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
@@ -54,3 +56,18 @@ def test_tracer_batch_block_reports_both_ceilings():
     assert 0 < r["hbm_frac"] < 1 and 0 < r["valu_frac"] < 1.2
     # BT = 8 nzm (T (2 nx + 11) + 2 nx + 12) per instance
     assert r["algorithmic_bytes_per_launch"] == 65536 * 8 * 27 * (25 * (2 * 32 + 11) + 2 * 32 + 12)
+
+
+def test_side_blocks_of_round_3():
+    d = _record()
+    # the round-2 protocol is there as what it is, and is not slower than the cold headline
+    sh = d["consecutive_tracers_shared_uw"]
+    assert "NOT a cold call" in sh["workload"] and sh["roofline"]["frac"] >= d["roofline"]["frac"] - 0.01
+    # one step on fresh reference-layout u, w: the velocities' layout entry is inside the timed region
+    fu = d["step_with_fresh_uw"]
+    assert "mpdata_plan_run_uw" in fu["workload"] and 0.5 < fu["roofline"]["frac"] < d["roofline"]["frac"]
+    assert fu["roofline"]["algorithmic_bytes_per_launch"] == d["roofline"]["algorithmic_bytes_per_launch"]
+    lc = d["layout_conversion"]
+    assert lc["import_ms_u_and_w"] > 0 and lc["import_ms_f_per_tracer"] > 0 and lc["export_ms_f_per_tracer"] > 0
+    r = d["tracer_batched"]["roofline"]
+    assert "recorded profile" in r["valu_source"] and 0 < r["binding_floor_frac"] < 1.2

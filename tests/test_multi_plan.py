@@ -138,3 +138,55 @@ def test_shard_plans_are_ordinary_plans(mpdata, oracle, monkeypatch):
         assert np.array_equal(to_host(blk["f"]), f_ref[sl0:sl0 + nloc])
     assert L.mpdata_plan_shard_plan(p._p, 5) is None
     p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,T,shape", [([0, 0], 1, (131, 32, 28)), ([0, 0, 0], 2, (100, 9, 12))])
+def test_device_origin_scatter_gather_equals_single_plan(mpdata, oracle, monkeypatch, devices, T, shape):
+    """Arrays of the GLOBAL problem on the root GPU (mpdata_plan_import_device / _export_device on the
+    multi-GPU plan): pack kernel + peer transfers, every array queued behind the previous one without a
+    host synchronisation in between.  With every rank on device 0 the transport is the peer-copy one
+    (events order the reuse of the packed buffers); the RCCL branch of the same code runs in
+    tests/test_multi_fake_rccl.py.  Bitwise equal to a single-GPU plan, twice in a row (buffer reuse)."""
+    import torch
+    from util import to_dev, to_host
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    monkeypatch.delenv("MPDATA_MULTI_XFER", raising=False)
+    inp = _make(oracle, *shape, T)
+    f1, fl1 = _single(M, inp, T)
+    d = {k: to_dev(v) for k, v in inp.items()}
+    p = M.Plan(*shape, T, devices=devices)
+    for _ in range(2):
+        p.import_device(d["f"], d["u"], d["w"], d["rho"], d["rhow"], d["adz"], d["flux"])
+        p.run(); p.sync()
+        fo, flo = torch.empty_like(d["f"]), torch.empty_like(d["flux"])
+        p.export_device(fo, flo)
+        assert np.array_equal(to_host(fo), f1) and np.array_equal(to_host(flo), fl1)
+    st = p.transfer_stats()
+    assert st["transport"] == "p2p" and st["scatter_bytes_per_peer"] > 0 and st["gather_bytes_per_peer"] > 0
+    assert p.ranks_seen == 0      # no RCCL communicator: RCCL refuses two ranks on one device
+    p.close()
+
+
+@pytest.mark.gpu
+def test_plan_timing_switch(mpdata, oracle):
+    """mpdata_plan_set_timing(0): no event pair around the runs, last_kernel_ms says so; results unchanged."""
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    inp = _make(oracle, 64, 32, 28, 1)
+    f1, fl1 = _single(M, inp, 1)
+    p = M.Plan(64, 32, 28, 1)
+    p.set_timing(False)
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run(); p.sync()
+    with pytest.raises(M.MpdataError):
+        p.last_kernel_ms()
+    f = np.empty_like(inp["f"], order="F"); flux = np.empty_like(inp["flux"], order="F")
+    p.download(f, flux)
+    assert np.array_equal(f, f1) and np.array_equal(flux, fl1)
+    p.set_timing(True)
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run(); p.sync()
+    assert p.last_kernel_ms() > 0
+    p.close()
