@@ -34,7 +34,7 @@ int g_kernel = -2;   // -2: read NLK_KERNEL on first use; -1 automatic, 0 one le
 int kernel_mode() {
   if (g_kernel == -2) {
     const char* f = getenv("NLK_KERNEL");
-    g_kernel = f ? (atoi(f) != 0) : -1;
+    g_kernel = f ? atoi(f) : -1;
   }
   return g_kernel;
 }
@@ -133,7 +133,7 @@ int nlk_set_variant(int v) {
 int nlk_get_variant(void) { return variant(); }
 int nlk_set_kernel(int mode) {
   const int prev = kernel_mode();
-  if (mode >= -1 && mode <= 1) g_kernel = mode;
+  if (mode >= -1 && mode <= 2) g_kernel = mode;
   return prev;
 }
 int64_t nlk_algorithmic_bytes(int nEdges, int nCells, int nVertLevels, int nvldim, int nAdv) {

@@ -240,13 +240,95 @@ __global__ void __launch_bounds__(64 * NLK_WAVES) nlk_kernel_x2(const NlkArgs g)
   }
 }
 
-// mode: -1 automatic, 0 one level per lane, 1 two levels per lane (where alignment allows)
+// ---- the same, with the per-cell bookkeeping in the VECTOR unit.  Even batched, the scalar form above
+// spends ~25 scalar instructions per cell on the CU's one scalar unit (index checks, two level-range
+// loads, clamps, range end, column offset).  Here lane i < nadv owns cell i of the edge and does all of
+// that once, for all cells at the same time, in a dozen vector instructions (the cell list, the two
+// coefficients and the level range arrive as vector loads of 10 lanes); what the gather of cell i needs
+// wave-uniform -- column offset and range end -- comes out of the lanes by v_readlane (executed by the
+// vector pipes, of which a CU has four).  Needs nAdv <= 64.
+__global__ void __launch_bounds__(64 * NLK_WAVES) nlk_kernel_x2v(const NlkArgs g) {
+  const int lane = threadIdx.x & 63;
+  const int iEdge = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * NLK_WAVES + (threadIdx.x >> 6)));
+  if (iEdge >= g.nEdges) return;
+  const long long erow = (long long)g.nvldim * iEdge;
+  int nadv = sload(g.nAdvCellsForEdge + iEdge);
+  nadv = nadv < g.nAdv ? nadv : g.nAdv;
+  const unsigned colB = (unsigned)g.nvldim * 8u;   // bytes of a cell's column
+  // ---- lane i: cell i of the edge
+  const bool mine = lane < nadv;
+  const long long cpos = (long long)g.nAdv * iEdge + lane;
+  const int cellv = mine ? g.advCellsForEdge[cpos] : 0;
+  const double c1v = mine ? g.advCoefs[cpos] : 0.0;
+  const double c3v = (mine ? g.advCoefs3rd[cpos] : 0.0) * g.coef3rdOrder;
+  const bool okv = (unsigned)(cellv - 1) < (unsigned)g.nCells;   // (a cell out of range: the reference would read out of bounds)
+  const unsigned icv = okv ? (unsigned)(cellv - 1) : 0u;
+  const int kminv = okv ? g.minLevelCell[icv] : 1;
+  int kmv = okv ? g.maxLevelCell[icv] : 0;
+  kmv = kmv < g.nVertLevels ? kmv : g.nVertLevels;
+  kmv = kmv > 0 ? kmv : 0;
+  // levels 1 .. kmax of the cell's column: the range check sees scalar + per-lane offset, so the range ends
+  // at column start + 8 kmax (nothing to read: ends at the column start)
+  const unsigned cbv = icv * colB;
+  const unsigned nrecv = cbv + (unsigned)kmv * 8u;
+  const bool any_kmin = __builtin_amdgcn_ballot_w64(kminv > 1) != 0ull;   // some cell starts above level 1 (usual case: none, :60)
+  auto rl_d = [](const double v, const int j) __attribute__((always_inline)) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
+  };
+  for (int k0 = 0; k0 < g.nVertLevels; k0 += 128) {
+    const int kA = k0 + 2 * lane + 1, kB = kA + 1;   // the lane's two (1-based) levels
+    const bool lA = kA <= g.nVertLevels, lB = kB <= g.nVertLevels;
+    const unsigned koff = (unsigned)(kA - 1) * 8u;
+    nlk_f64x2 ntf = {0.0, 0.0}, msk = {0.0, 0.0};
+    if (lA) {   // (kB = nVertLevels + 1 reads the row's padding: nvldim is even, so it exists; that half is never stored)
+      ntf = *reinterpret_cast<const nlk_f64x2*>(g.normalThicknessFlux + erow + kA - 1);
+      msk = *reinterpret_cast<const nlk_f64x2*>(g.advMaskHighOrder + erow + kA - 1);
+    }
+    double wgt[2], sgn[2], acc[2] = {0.0, 0.0};
+    wgt[0] = ntf.x * msk.x; wgt[1] = ntf.y * msk.y;                                        // :126-127
+    sgn[0] = __builtin_copysign(1.0, ntf.x); sgn[1] = __builtin_copysign(1.0, ntf.y);      // :128-129
+    constexpr int CH = NLK_CH2;
+    for (int i0 = 0; i0 < nadv; i0 += CH) {                                                // :136-148
+      double tv[CH][2];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const bool have = i0 + j < nadv;       // (wave-uniform; a missing cell: empty range, reads zeros)
+        const int jj = have ? i0 + j : 0;
+        const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)cbv, jj);
+        const unsigned nrec = have ? (unsigned)__builtin_amdgcn_readlane((int)nrecv, jj) : 0u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(g.tracerCur), (short)0, (int)nrec, 0x00020000);
+        const nlk_f64x2 v = __builtin_bit_cast(nlk_f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)koff, (int)cb, 0));
+        tv[j][0] = v.x; tv[j][1] = v.y;
+      }
+      if (any_kmin) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const int kmin = __builtin_amdgcn_readlane(kminv, i0 + j < nadv ? i0 + j : 0);
+          tv[j][0] = kA >= kmin ? tv[j][0] : 0.0;
+          tv[j][1] = kB >= kmin ? tv[j][1] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int jj = i0 + j < nadv ? i0 + j : 0;
+        const double c1 = rl_d(c1v, jj), c3 = rl_d(c3v, jj);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = acc[t] + tv[j][t] * wgt[t] * (c1 + c3 * sgn[t]);
+      }
+    }
+    if (lB) *reinterpret_cast<nlk_f64x2*>(g.highOrderFlx + erow + kA - 1) = nlk_f64x2{acc[0], acc[1]};
+    else if (lA) g.highOrderFlx[erow + kA - 1] = acc[0];
+  }
+}
+
+// mode: -1 automatic, 0 one level per lane, 1 two levels per lane with scalar bookkeeping, 2 ... with vector bookkeeping
 void launch(const NlkArgs& g, void* stream, int mode) {
   const unsigned gx = (unsigned)((g.nEdges + NLK_WAVES - 1) / NLK_WAVES);
   const uintptr_t al = (uintptr_t)g.tracerCur | (uintptr_t)g.normalThicknessFlux | (uintptr_t)g.advMaskHighOrder |
                        (uintptr_t)g.highOrderFlx;
   const bool can = (g.nvldim & 1) == 0 && (al & 15) == 0 && (double)g.nCells * g.nvldim * 8.0 < 4294967000.0;
-  if (can && mode != 0) hipLaunchKernelGGL(nlk_kernel_x2, dim3(gx), dim3(64 * NLK_WAVES), 0, (hipStream_t)stream, g);
+  if (can && g.nAdv <= 64 && (mode == 2 || mode < 0)) hipLaunchKernelGGL(nlk_kernel_x2v, dim3(gx), dim3(64 * NLK_WAVES), 0, (hipStream_t)stream, g);
+  else if (can && mode != 0) hipLaunchKernelGGL(nlk_kernel_x2, dim3(gx), dim3(64 * NLK_WAVES), 0, (hipStream_t)stream, g);
   else hipLaunchKernelGGL(nlk_kernel, dim3(gx), dim3(64 * NLK_WAVES), 0, (hipStream_t)stream, g);
 }
 

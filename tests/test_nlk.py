@@ -118,7 +118,7 @@ def test_hip_exact_reproduces_reference_golden_bitwise(K):
                                    (500, 70, 100, 10, 104), (9, 300, 200, 12, 200), (64, 5, 3, 2, 8)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("variant", [0, 1], ids=["exact", "fast"])
-@pytest.mark.parametrize("kernel", [0, 1], ids=["one-level-per-lane", "two-levels-per-lane"])
+@pytest.mark.parametrize("kernel", [0, 1, 2], ids=["one-level-per-lane", "two-levels-per-lane", "two-levels-vector-bookkeeping"])
 def test_hip_matches_oracle(K, N, shape, variant, kernel):
     """The shipped namelist size; level counts around the wave width; padded leading dimension
     (nvldim > nVertLevels: padding rows stay untouched); ragged nAdvCellsForEdge, minLevelCell > 1,
@@ -147,7 +147,7 @@ def test_hip_larger_mesh_ragged_bitwise(K, N):
     K.set_variant(K.VARIANT_EXACT)
     inp = N.make_inputs(40000, 900, 40, 10, seed=77, ragged=True)
     ref = N.high_order_flux(inp)[:40]
-    for mode in (1, -1, 0):
+    for mode in (2, 1, -1, 0):
         K.set_kernel(mode)
         assert np.array_equal(run_hip(K, inp)[:40], ref), mode
     K.set_kernel(-1)

@@ -32,7 +32,7 @@ cases = [("streams only", dict(base, nAdvCellsForEdge=torch.zeros((nE,), dtype=t
          ("one cell", dict(base, advCellsForEdge=torch.ones((nE, nA), dtype=torch.int32, device=dev))),
          ("local", base), ("random", dict(base, advCellsForEdge=rand)),
          ("short columns", dict(base, maxLevelCell=torch.full((nC,), 3, dtype=torch.int32, device=dev)))]
-for mode in (1, 0):
+for mode in (2, 1, 0):
     K.set_kernel(mode)
     for name, d in cases:
         for _ in range(3):
