@@ -785,9 +785,14 @@ int mpdata_plan_run(mpdata_plan* p) {
 int mpdata_plan_run_uw(mpdata_plan* p, int first, int count, const void* u, const void* w) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
   if (!u || !w) return set_err(MPDATA_EINVAL, "null array pointer");
-  if (p->multi) return set_err(MPDATA_EUNSUPPORTED, "mpdata_plan_run_uw on a multi-GPU plan: use the shard plans");
   int rc = tracer_range(p, first, count);
   if (rc) return rc;
+  if (p->multi) {   // u, w: full-width arrays on the root GPU -- scatter them (RCCL over xGMI), then every GPU runs
+    rc = mpdata_multi_scatter_device(p->multi, nullptr, u, w, nullptr, nullptr, nullptr, nullptr, 0, 0);
+    if (!rc) rc = mpdata_multi_run(p->multi, first, count);
+    if (!rc) p->ran = true;
+    return rc;
+  }
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run_uw before upload / import");
   DevGuard g(p->device);
   if (p->timing) HIP_TRY(hipEventRecord(p->ev0, p->stream));

@@ -114,7 +114,8 @@ int mpdata_plan_run_tracers(mpdata_plan* plan, int first_tracer, int ntracers); 
  * wave-major plan: a kernel that reads u, w straight from the reference layout (128-byte row
  * segments through an LDS ring shared by the 8 waves of a workgroup) while f streams in the
  * plan layout -- no conversion pass; tracer batches: one fused u+w conversion, then the batch
- * kernel (the plan's u, w are then the new ones). */
+ * kernel (the plan's u, w are then the new ones).  On a multi-GPU plan u, w are full-width
+ * arrays on the root GPU: they are scattered (section 3b), then every GPU runs. */
 int mpdata_plan_run_uw(mpdata_plan* plan, int first_tracer, int ntracers, const void* u, const void* w);
 int mpdata_plan_sync(mpdata_plan* plan);           /* the `!$acc wait` (:237) */
 int mpdata_plan_download(mpdata_plan* plan, double* f, double* flux);  /* host arrays */

@@ -190,3 +190,27 @@ def test_plan_timing_switch(mpdata, oracle):
     p.run(); p.sync()
     assert p.last_kernel_ms() > 0
     p.close()
+
+
+@pytest.mark.gpu
+def test_multi_plan_run_uw_scatters_fresh_velocities(mpdata, oracle):
+    """mpdata_plan_run_uw on a multi-GPU plan: u, w = full-width arrays on the root GPU, scattered, then every
+    shard runs; the plan was filled with OTHER velocities.  Equal to the oracle on (f, u, w)."""
+    from util import to_dev, to_host
+    import torch
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    shape = (150, 32, 28)
+    inp = _make(oracle, *shape, 1)
+    other = oracle.make_inputs(*shape, seed=1234, dist=3)
+    d = {k: to_dev(v) for k, v in inp.items()}
+    p = M.Plan(*shape, 1, devices=[0, 0, 0])
+    p.import_device(d["f"], to_dev(other["u"]), to_dev(other["w"]), d["rho"], d["rhow"], d["adz"], d["flux"])
+    p.run_uw(d["u"], d["w"])
+    p.sync()
+    fo, flo = torch.empty_like(d["f"]), torch.empty_like(d["flux"])
+    p.export_device(fo, flo)
+    p.close()
+    f_ref, flux_ref = oracle.advect(inp, nthreads=4)
+    assert np.array_equal(to_host(fo), f_ref)
+    assert np.allclose(to_host(flo)[:, :-1], flux_ref[:, :-1], rtol=1e-13, atol=1e-13)
