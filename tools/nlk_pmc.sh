@@ -5,12 +5,12 @@ cd /tmp && export TMPDIR=/tmp
 N="python3 $ROOT/tools/nlk_bench.py 3"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d $OUT/a -o run -- $N > $OUT/a.log 2>&1
 rocprofv3 --pmc SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/b -o run -- $N > $OUT/b.log 2>&1
-rocprofv3 --pmc TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/c -o run -- $N > $OUT/c.log 2>&1
+# (a third pass with TA_* / TCP_* derived counters aborted inside rocprofv3 on this pool and hung the call: not run)
 cd $ROOT
 python3 - <<'PY'
 import csv, glob, os
 out = os.path.join("gpurun_out", "nlk_pmc")
-for p in ("a", "b", "c"):
+for p in ("a", "b"):
     f = glob.glob(os.path.join(out, p, "**", "*_counter_collection.csv"), recursive=True)
     if not f:
         print(p, "no csv"); continue
