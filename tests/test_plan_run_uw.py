@@ -108,6 +108,34 @@ def test_run_uw_tracer_batch_converts(M, oracle):
     run_uw_case(M, oracle, (50, 7, 12), "exact", dist=1, seed=10, ntr=2)
 
 
+def test_run_uw_one_tracer_of_a_multi_tracer_plan(M, oracle):
+    """run_uw(first_tracer=1, ntracers=1) on a 3-tracer plan: the kernel that reads u, w from the reference
+    layout works on that tracer alone; the other two keep their fields, and the plan's OWN u, w are untouched
+    (a later plain run of tracer 2 still uses the uploaded ones)."""
+    import torch
+    M.set_variant(M.VARIANT_EXACT)
+    ncrms, nx, nz = 96, 32, 28
+    inp = oracle.make_inputs(ncrms, nx, nz, seed=41, dist=3)
+    other = oracle.make_inputs(ncrms, nx, nz, seed=42, dist=3)
+    fs = [oracle.make_inputs(ncrms, nx, nz, seed=430 + t, dist=3)["f"] for t in range(3)]
+    up = dict(inp, u=other["u"], w=other["w"])
+    up["f"] = np.asfortranarray(np.stack(fs, axis=-1))
+    up["flux"] = np.asfortranarray(np.stack([inp["flux"]] * 3, axis=-1))
+    p = M.Plan(ncrms, nx, nz, 3)
+    p.upload(up["f"], up["u"], up["w"], up["rho"], up["rhow"], up["adz"], up["flux"])
+    p.run_uw(to_dev(inp["u"]), to_dev(inp["w"]), first_tracer=1, ntracers=1)
+    p.run(2, 1)            # tracer 2 with the plan's own (other) velocities
+    p.sync()
+    f = np.empty_like(up["f"], order="F"); flux = np.empty_like(up["flux"], order="F")
+    p.download(f, flux)
+    p.close()
+    assert np.array_equal(f[..., 0], fs[0])                                        # untouched
+    f1_ref, _ = oracle.advect(dict(inp, f=fs[1].copy()), nthreads=4)               # fresh u, w
+    assert np.array_equal(f[..., 1], f1_ref)
+    f2_ref, _ = oracle.advect(dict(inp, u=other["u"], w=other["w"], f=fs[2].copy()), nthreads=4)   # the plan's u, w
+    assert np.array_equal(f[..., 2], f2_ref)
+
+
 def test_run_uw_unaligned_bases_convert(M, oracle):
     run_uw_case(M, oracle, (64, 32, 28), "exact", dist=3, seed=11, misalign=True)
 
