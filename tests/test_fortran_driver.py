@@ -138,3 +138,45 @@ def test_driver_tracers_and_gpus(oracle, tmp_path, ntr, ngpus, use_nml):
     nzm = nz - 1
     assert np.all(np.abs(flux[:, :nzm] - flux_ref[:, :nzm]) <= 1e-13 * np.maximum(1.0, np.abs(flux_ref[:, :nzm])))
     assert np.array_equal(flux[:, nzm], inp["flux"][:, nzm])
+
+
+def _checksums(out):
+    import re
+    f = re.search(r"checksum f\s*:\s*([0-9.Ee+-]+)", out)
+    x = re.search(r"checksum flux\s*:\s*([0-9.Ee+-]+)", out)
+    assert f and x, out
+    return float(f.group(1)), float(x.group(1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ntr,ngpus,fake_rccl", [(1, 1, False), (3, 2, False), (2, 3, True)])
+def test_driver_device_mode(oracle, ntr, ngpus, fake_rccl):
+    """mode = device: the global arrays are generated on the root GPU (the law init() uses), scattered from
+    there, advected, gathered and summed on the device -- no host array of the problem's size (what
+    BASELINE.json configs[4] needs).  Checked through the printed checksums against the oracle on the same
+    law.  With ngpus > 1 every rank sits on device 0: the peer-copy transport, or -- the driver run against
+    the test-only link of the library with the recording RCCL stand-in (LD_PRELOAD, MPDATA_MULTI_FORCE_RCCL) --
+    the RCCL branch, which then reports its ranks."""
+    assert os.path.exists(EXE), "Fortran driver not built"
+    ncrms, nx, nz, dist = 96, 32, 28, 1
+    inp = oracle.make_inputs(ncrms, nx, nz, seed=100, dist=dist, ntracers=ntr)
+    f_ref, flux_ref = oracle.advect(inp, nthreads=4)
+    env = dict(os.environ, MPDATA_MULTI_DEVICES=",".join(["0"] * ngpus))
+    if fake_rccl:
+        fake = os.path.join(ROOT, "tests", "stubs", "libmpdata_hip_fakerccl.so")
+        if not os.path.exists(fake):
+            pytest.skip("tests/stubs/libmpdata_hip_fakerccl.so not built")
+        env.update(LD_PRELOAD=fake, MPDATA_MULTI_FORCE_RCCL="1")
+    res = subprocess.run([EXE, str(ncrms), str(nx), str(nz), str(dist), "0", "-", "-", str(ntr), str(ngpus), "device"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "mode: device" in res.stdout and "HIP kernel (hipEvent) seconds" in res.stdout
+    sf, sx = _checksums(res.stdout)
+    nzm = nz - 1
+    assert sf == pytest.approx(float(f_ref.sum()), rel=1e-12)
+    assert sx == pytest.approx(float(flux_ref[:, :nzm].sum()), rel=1e-10, abs=1e-9)
+    import re
+    ranks = int(re.search(r"RCCL ranks seen[^:]*:\s*(\d+)", res.stdout).group(1))
+    assert ranks == (ngpus if fake_rccl else 0)
+    if ngpus > 1:
+        assert "scatter seconds" in res.stdout and "gather  seconds" in res.stdout
