@@ -311,6 +311,7 @@ struct Window {
   R UR[3], UD[3], PW[3], SW[3], WR[3];         // u, u(kb), w+w(kc), w-sum, w of column q
   R SU[3], U2P[3], U2N[3];                     // written for column q-1 (pp / pn of U2)
   R MXN[3], MNN[3], U3[3], DW3[3];             // written for column q-2
+  R SF[3];                                     // wave-major two-tracer FAST form only: f1 + f1(kb) of column q-1
 };
 
 // BIG: some array is 4 GiB or larger.  Then every buffer descriptor starts at the first row

@@ -196,6 +196,13 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #else
   constexpr bool XNEW = TPW == 2;   // the 7-operation extrema (stage A below): where the registers allow it
 #endif
+  // FAST, two tracers per wave (the VALU- / power-bound form): three operations per tracer and column fewer
+  // by carrying sums in the rings and sharing the velocity parts of the upwind fluxes (below: XSUM)
+#if defined(MPDATA_FAST_DIV) && !defined(MPDWM_NO_XSUM)
+  constexpr bool XSUM = XNEW;
+#else
+  constexpr bool XSUM = false;
+#endif
   constexpr int SLP = T::SLP, RB = (int)sizeof(R);
   __shared__ R lds[T::LDS_ELEMS];
 
@@ -506,7 +513,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     S.F1[j] = S.F1D[j] = S.F1U[j] = S.MX0[j] = S.MN0[j] = ZV;
     G.UR[j] = G.UD[j] = G.PW[j] = G.SW[j] = G.WR[j] = G.SU[j] = R(0);
     S.U2P[j] = S.U2N[j] = ZV;
-    S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = ZV;
+    S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = S.SF[j] = ZV;
   }
   V S1 = ZV, S3 = ZV;
   V v_def = ZV;   // the deferred store of a pair's odd column
@@ -582,9 +589,15 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     V U1q = ZV, DW1q = ZV, f1_1 = ZV, F1D_1 = ZV, F1U_1 = ZV, MX0_1 = ZV, MN0_1 = ZV;
     [[maybe_unused]] V G1mx = F0p, G1mn = F0p;   // G of column q-1 (an inactive step: never used by a valid star)
     if (FULL || (q >= -1 && q <= nx + 3)) {
-      U1q = upwind(uq, F0p, f0q);  // :532
+      // XSUM: max(0,u) f(ib) + min(0,u) f(i) as written (:532) -- one product is an exact zero, so the value is
+      // the select form's; the two velocity parts are formed once for the wave's tracers: a multiply and an
+      // FMA per tracer instead of a 64-bit select and a multiply
+      if constexpr (XSUM) U1q = dmax(uq, R(0)) * F0p + dmin(uq, R(0)) * f0q;
+      else U1q = upwind(uq, F0p, f0q);  // :532
       if (FULL || q <= nx + 2) {
-        const V W1q = upwind(wq, f0d, f0q);  // :537
+        V W1q;
+        if constexpr (XSUM) W1q = dmax(wq, R(0)) * f0d + dmin(wq, R(0)) * f0q;
+        else W1q = upwind(wq, f0d, f0q);  // :537
         DW1q = UP_G(W1q) - W1q;
         if (FULL || (q >= 1 && q <= nx)) S1 = S1 + W1q;  // :545 (UWREF: S1 also takes the limited terms)
       }
@@ -616,7 +629,14 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     S.DW1[C0] = DW1q;
     S.F1[C1] = f1_1;
     S.F1D[C1] = F1D_1;
-    S.F1U[C1] = F1U_1;
+    // XSUM: the ring carries f1(kc) - f1(kb) and f1 + f1(kb) of the column (the cross terms of :573 / :582 take
+    // differences of such sums over neighbouring columns: 2 operations each instead of 3)
+    if constexpr (XSUM) {
+      S.F1U[C1] = F1U_1 - F1D_1;
+      S.SF[C1] = F1D_1 + f1_1;
+    } else {
+      S.F1U[C1] = F1U_1;
+    }
     S.MX0[C1] = MX0_1;
     S.MN0[C1] = MN0_1;
     // :521-522 for column q without its f(ic) term
@@ -680,7 +700,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #ifdef MPDATA_FAST_DIV
         const R u1 = G.UR[C1];
         const R t1 = rabs(u1) - (u1 * u1) * IRHO;
-        const V x4 = S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1;
+        V x4;
+        if constexpr (XSUM) x4 = S.F1U[C2] + S.F1U[C1];   // (the ring holds f1(kc) - f1(kb))
+        else x4 = S.F1U[C2] + F1U_1 - S.F1D[C2] - F1D_1;
         U2_1 = t1 * (f1_1 - S.F1[C2]) - (KU * (u1 * G.SW[C1])) * x4;   // = 2 x (:571-573)
 #else
         const V ad = andiff_s(S.F1[C2], f1_1, G.UR[C1], IRHO);
@@ -695,7 +717,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #ifdef MPDATA_FAST_DIV
           const R w2 = G.WR[C2];
           const R t1 = rabs(w2) - (w2 * w2) * IRHOW;
-          const V x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
+          V x4;
+          if constexpr (XSUM) x4 = S.SF[C1] - S.SF[C3];   // (the ring holds f1 + f1(kb))
+          else x4 = F1D_1 + f1_1 - S.F1D[C3] - S.F1[C3];
           // (0.0625 on the non-constant factor: exact scaling, and no per-lane constant for the compiler to keep)
           if constexpr (UWREF) W2_2 = t1 * (S.F1[C2] - S.F1D[C2]) - (IRHO * (w2 * G.SU[C2])) * (R(0.0625) * x4);
           else W2_2 = t1 * (S.F1[C2] - S.F1D[C2]) - (KW * (w2 * G.SU[C2])) * x4;  // = 2 x (:580-582); k = 1: 0

@@ -204,6 +204,9 @@ const char* build_flags() {
 #ifdef MPDWM_EXTREMA_OLD
          " MPDWM_EXTREMA_OLD"
 #endif
+#ifdef MPDWM_NO_XSUM
+         " MPDWM_NO_XSUM"
+#endif
 #if MPDWX_UW_POS != 1
          " MPDWX_UW_POS"
 #endif
