@@ -3,7 +3,7 @@
 hbm_traffic.json (the per-launch HBM bytes bench.py quotes as `roofline.traffic`, with their source)."""
 import csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")

@@ -2,11 +2,11 @@
 # Round profile: kernel-trace stats + separate PMC passes of the headline bench (1 tracer, plan
 # API, wave-major layout) and of the 25-tracer batch, then tools/pmc_summary.py writes the
 # summaries the judge reads into profiles/.
-#   usage (on the GPU box):  bash tools/profile_round.sh r02
+#   usage (on the GPU box):  bash tools/profile_round.sh r03   (tools/record_round.sh runs it with the other records of a round)
 # rocprofv3 rules of this pool: the program itself after `--`; --pmc never together with
 # --kernel-trace/--stats; one counter group per pass.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
