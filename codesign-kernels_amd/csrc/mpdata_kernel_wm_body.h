@@ -191,10 +191,24 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   static_assert(TPW == 1 || (TPW == 2 && !STREAM), "two tracers per wave: batch form only");
   static_assert(!UWREF || (STREAM && TPW == 1), "u, w from the reference layout: one tracer per launch");
   using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
+  // T1X (FAST, fp64, one tracer per wave): the 7-operation extrema and the ring sums of the two-tracer form
+  // (XNEW, XSUM below: 6 operations per column fewer) in 128 VGPRs.  The registers come from: rho folded into
+  // the limiter's reciprocal, one flux accumulator, ONE ring value dW/adz - U per column instead of U and dW
+  // (ESUM), the flux position formed again behind the march.  +1 % on the headline; in the u, w-ring form it
+  // spills (-DMPDWM_UW_X: -7 %), and in the two-tracer form ESUM alone costs 1 % (scheduling): both left as they were.
+#if !defined(MPDWM_NO_T1X) && defined(MPDATA_FAST_DIV) && !defined(MPDWM_EXTREMA_OLD)
+#ifdef MPDWM_UW_X
+  constexpr bool T1X = TPW == 1 && std::is_same<R, double>::value;
+#else
+  constexpr bool T1X = TPW == 1 && !UWREF && std::is_same<R, double>::value;
+#endif
+#else
+  constexpr bool T1X = false;
+#endif
 #ifdef MPDWM_EXTREMA_OLD
   constexpr bool XNEW = false;
 #else
-  constexpr bool XNEW = TPW == 2;   // the 7-operation extrema (stage A below): where the registers allow it
+  constexpr bool XNEW = TPW == 2 || T1X;   // the 7-operation extrema (stage A below): where the registers allow it
 #endif
   // FAST, two tracers per wave (the VALU- / power-bound form): three operations per tracer and column fewer
   // by carrying sums in the rings and sharing the velocity parts of the upwind fluxes (below: XSUM)
@@ -203,6 +217,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #else
   constexpr bool XSUM = false;
 #endif
+  constexpr bool ESUM = T1X;
   constexpr int SLP = T::SLP, RB = (int)sizeof(R);
   __shared__ R lds[T::LDS_ELEMS];
 
@@ -602,7 +617,10 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         if (FULL || (q >= 1 && q <= nx)) S1 = S1 + W1q;  // :545 (UWREF: S1 also takes the limited terms)
       }
       if (FULL || q >= 0) {
-        f1_1 = F0p - ((U1q - S.U1[C1]) + S.DW1[C1] * IADZ) * IRHO;  // :557, column q-1
+        // ESUM: the ring carries the column's own share  dW1 / adz - U1  of the next column's update (one value
+        // instead of two; same operation count)
+        if constexpr (ESUM) f1_1 = F0p - (U1q + S.DW1[C1]) * IRHO;
+        else f1_1 = F0p - ((U1q - S.U1[C1]) + S.DW1[C1] * IADZ) * IRHO;  // :557, column q-1
         F1D_1 = DN_C(f1_1);
         F1U_1 = UP_C(f1_1);
         if constexpr (!XNEW) {
@@ -625,8 +643,12 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         if (!FULL && q - 1 >= nx + 1) st_col(q - 1 <= nx + 2, q + 1, f1_1, std::integral_constant<int, 2>{});
       }
     }
-    S.U1[C0] = U1q;
-    S.DW1[C0] = DW1q;
+    if constexpr (ESUM) {
+      S.DW1[C0] = DW1q * IADZ - U1q;
+    } else {
+      S.U1[C0] = U1q;
+      S.DW1[C0] = DW1q;
+    }
     S.F1[C1] = f1_1;
     S.F1D[C1] = F1D_1;
     // XSUM: the ring carries f1(kc) - f1(kb) and f1 + f1(kb) of the column (the cross terms of :573 / :582 take
@@ -748,7 +770,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #ifdef MPDATA_FAST_DIV
         {  // one reciprocal for both ratios (both denominators >= eps > 0, finite)
           const V dd2 = den_mx * den_mn;
-          const V r = RHO * recip_nr(dd2);   // (rho once for both ratios)
+          V r;
+          if constexpr (T1X) r = recip_nr(dd2 * IRHO);   // (no rho register)
+          else r = RHO * recip_nr(dd2);   // (rho once for both ratios)
           MXN_2 = (mx1 - S.F1[C2]) * (den_mn * r);
           MNN_2 = (S.F1[C2] - mn1) * (den_mx * r);
         }
@@ -774,7 +798,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         const V mxd = DN_C(MXN_2);
         const V mnd = DN_C(MNN_2);
         const V W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
-        if constexpr (UWREF) S1 = S1 + W3;  // one accumulator (two registers that kernel does not have)
+        if constexpr (UWREF || T1X) S1 = S1 + W3;  // one accumulator (two registers that kernel does not have)
         else S3 = S3 + W3;  // :624
         DW3_2 = UP_G(W3) - W3;
       }
@@ -784,7 +808,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
       const bool act = n >= -1 && n <= nx + 2;
       V v = S.F1[C3];  // halo columns keep the first-pass value (:557)
       if (FULL || (n >= 1 && n <= nx))
-        v = dmax(ZV, S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
+        v = ESUM ? dmax(ZV, S.F1[C3] - (U3_2 + S.DW3[C3]) * IRHO)
+                 : dmax(ZV, S.F1[C3] - ((U3_2 - S.U3[C3]) + S.DW3[C3] * IADZ) * IRHO);  // :634
       // the odd column's store waits until the next pair has been waited for: the counted wait
       // must see every store issued after the pair's DMA complete, and a store issued right
       // before it would stall it for a store round trip (+1 % one tracer, +3.5 % tracer batches)
@@ -796,8 +821,12 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         st_col(FULL || act, max(n + 2, 0), v, std::integral_constant<int, 0>{});
       }
     }
-    S.U3[C2] = U3_2;
-    S.DW3[C2] = DW3_2;
+    if constexpr (ESUM) {
+      S.DW3[C2] = DW3_2 * IADZ - U3_2;
+    } else {
+      S.U3[C2] = U3_2;
+      S.DW3[C2] = DW3_2;
+    }
   };
 #undef DN_C
 #undef UP_C
@@ -916,8 +945,18 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 
   if constexpr (TPW == 1) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
   {  // flux (:541-547, :624)
-    const V fl = UWREF ? S1 : S1 + S3;
-    if (lvl_ok && tile_ok) flux[pos] = first(fl);
+    const V fl = (UWREF || T1X) ? S1 : S1 + S3;
+    int posf = pos;
+    bool okf = lvl_ok;
+    if constexpr (T1X) {   // the lane's element, formed again behind the march: no register carries it through
+      unsigned z;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      const int l2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+      const int kk2 = l2 % LPS;
+      okf = kk2 < nzm;
+      posf = (l2 / LPS) * nzm + (okf ? kk2 : nzm - 1);
+    }
+    if (okf && tile_ok) flux[posf] = first(fl);
     if constexpr (TPW == 2)
       if (lvl_ok && has1) flux1[pos] = second(fl);
   }

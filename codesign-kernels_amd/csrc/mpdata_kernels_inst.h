@@ -207,6 +207,12 @@ const char* build_flags() {
 #ifdef MPDWM_NO_XSUM
          " MPDWM_NO_XSUM"
 #endif
+#ifdef MPDWM_NO_T1X
+         " MPDWM_NO_T1X"
+#endif
+#ifdef MPDWM_UW_X
+         " MPDWM_UW_X"
+#endif
 #if MPDWX_UW_POS != 1
          " MPDWX_UW_POS"
 #endif
