@@ -317,6 +317,7 @@ int main(int argc, char** argv) {
       run<5, 3, 4, 2, 2>(f, u, w, f, ntiles, ncol, chunkB, tileB, "splitEXEC");
       run<5, 3, 4, 2, 2, 2, 6>(f, u, w, f, ntiles, ncol, chunkB, tileB, "safe wait");      // 2 in flight, stores not counted
       run<5, 3, 4, 2, 2, 3, 12>(f, u, w, f, ntiles, ncol, chunkB, tileB, "safe wait");     // 3 in flight (the kernel)
+      run<5, 3, 4, 2, 2, 3, 12>(f, u, w, fo, ntiles, ncol, chunkB, tileB, "safe, f -> fo");   // out of place
       run<5, 3, 4, 2, 2, 3, 16>(f, u, w, f, ntiles, ncol, chunkB, tileB, "3 ahead+st");    // 3 in flight, stores counted
       run<5, 3, 4, 2, 2, 3, 12, 2>(f, u, w, f, ntiles, ncol, chunkB, tileB, "rem st nt");       // remainder stores streaming as well
       run<5, 3, 4, 2, 2, 3, 12, 1>(f, u, w, f, ntiles, ncol, chunkB, tileB, "rem st sc0");
