@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off wider sweep than the test suite (round 3's new kernels), GPU:
   * mpdata_plan_run_uw, EXACT, bitwise vs the oracle: N random shapes (even and odd ncrms, nz 3..40, nx 1..60)
+  * one tracer, FAST, plan run: max |df| < 1e-12 and flux within 1e-12 (relative to max |flux|) on conditioned inputs
   * tracer batches (2..7 tracers) FAST vs the oracle (max |df| < 1e-12 on conditioned inputs) and EXACT bitwise
   * nlk: random meshes, ragged, every kernel form, EXACT bitwise
 usage: python tools/fuzz_round3.py [N]"""
@@ -34,6 +35,20 @@ for it in range(n):
     if not np.array_equal(f, f_ref):
         bad += 1; print("run_uw MISMATCH", ncrms, nx, nz, dist, np.abs(f - f_ref).max())
 print("run_uw cases", n, "bad", bad)
+# one tracer, FAST (the headline kernel's form: 7-operation extrema, ring sums, merged U / dW ring value): f and flux
+M.set_variant(M.VARIANT_FAST)
+for it in range(n):
+    ncrms = int(rng.integers(1, 400)); nx = int(rng.integers(1, 61)); nz = int(rng.integers(3, 65))
+    inp = O.make_inputs(ncrms, nx, nz, seed=40000 + it, dist=1)
+    p = M.Plan(ncrms, nx, nz, 1)
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"]); p.run(); p.sync()
+    f = np.empty_like(inp["f"], order="F"); fl = np.empty_like(inp["flux"], order="F")
+    p.download(f, fl); p.close()
+    f_ref, fl_ref = O.advect(inp, nthreads=4)
+    ef = np.abs(f - f_ref).max(); efl = np.abs(fl - fl_ref).max() / max(np.abs(fl_ref).max(), 1e-300)
+    if not (ef < 1e-12 and efl < 1e-12):
+        bad += 1; print("fast T=1 MISMATCH", ncrms, nx, nz, ef, efl)
+print("fast one-tracer cases", n, "bad", bad)
 for it in range(n // 2):
     ncrms = int(rng.integers(1, 300)); nx = int(rng.integers(1, 50)); nz = int(rng.integers(3, 65)); T = int(rng.integers(2, 8))
     base = O.make_inputs(ncrms, nx, nz, seed=100 + it, dist=1)
