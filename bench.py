@@ -76,6 +76,7 @@ def parse():
                     help="headline on ONE plan whose field sets share u, w (round-2 protocol); default: a plan per "
                          "field set with its own u, w")
     ap.add_argument("--no-fresh-uw", action="store_true", help="skip the step_with_fresh_uw side block")
+    ap.add_argument("--no-x2", action="store_true", help="skip the twice_the_instances side block")
     ap.add_argument("--no-shared-block", action="store_true", help="skip the shared-u,w side block")
     ap.add_argument("--layout", choices=["wavemajor", "reference"], default="wavemajor",
                     help="device layout of the plans the headline runs on (include/mpdata_hip.h section 3)")
@@ -685,6 +686,24 @@ def main():
                             f"device arrays EVERY step (distinct arrays per step, {nfs} sets), ncrms={n_loc}/GPU, 1 tracer",
                 "value": cells_1 * fsteps / dt7, "unit": "cell-updates/s", "steps": fsteps,
                 "ms_per_step": dt7 / fsteps * 1e3, "roofline": roofline_block(alg_bytes, kms7)}
+
+    # ---- side block: the headline protocol at TWICE the instances per GPU (north_star: "at ncrms >= 65 536"):
+    #      the fixed part of a launch (ramp, drain of the last wave round, gap to the next launch) halves ----
+    if not args.no_x2 and ntr == 1 and not f32 and not args.shared_uw:
+        n2 = 2 * n_loc
+        xsteps = min(steps, 16)
+        shared2, _, sh2 = make_shared(M, torch, dev, n2, n2 * world, rank * n2, nx, nz, args.dist, tdt)
+        dt8, kms8, info8 = bench_plan(M, torch, dist, world, dev, shared2, sh2["f"], n2, n2 * world, rank * n2, nx, nz, 1,
+                                      xsteps, SIDE_WARMUP, args.dist, npdt, tdt, 0.5 * mem_frac)
+        del shared2
+        torch.cuda.empty_cache()
+        if rank == 0:
+            result["twice_the_instances"] = {
+                "workload": f"the headline protocol (cold: a plan of its own per timed step, {info8['field_sets']} sets) at "
+                            f"ncrms={n2}/GPU nx={nx} nz={nz} fp64, 1 tracer",
+                "value": 2 * cells_1 * xsteps / dt8, "unit": "cell-updates/s", "steps": xsteps,
+                "ms_per_step": dt8 / xsteps * 1e3,
+                "roofline": roofline_block(M.algorithmic_bytes(n2, nx, nz, 1), kms8)}
 
     # ---- BASELINE configs[3] / [4]: 25 tracers per instance, every rank ---------------------
     if not args.no_batched and ntr == 1:

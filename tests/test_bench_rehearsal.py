@@ -35,4 +35,5 @@ def test_two_rank_bench_prints_one_whole_job_line():
     tb = d["tracer_batched"]
     assert tb["n_gpus"] == 2 and tb["steps"] == 2 and tb["value"] > 0 and "configs[4]" in tb["workload"]
     assert d["reference_layout_device_call"]["value"] > 0
+    assert d["twice_the_instances"]["value"] > 0 and "ncrms=8192/GPU" in d["twice_the_instances"]["workload"]
     assert "scatter_gather" in d      # (gloo cannot move device tensors: an error entry in the rehearsal)

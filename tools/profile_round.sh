@@ -14,11 +14,11 @@ cd /tmp && export TMPDIR=/tmp
 # every pass runs ONLY the block whose kernel it profiles (the side blocks launch kernels of the same
 # name at other sizes -- the chunked host call did, round 2 -- and tools/pmc_summary.py additionally keeps
 # only the full-size dispatches of a kernel)
-X="--no-cpu-baseline --no-fp32 --no-bwk --no-reflayout --no-host-call --no-shared-block --no-fresh-uw"
+X="--no-cpu-baseline --no-fp32 --no-bwk --no-reflayout --no-host-call --no-shared-block --no-fresh-uw --no-x2"
 B="python3 $ROOT/bench.py --steps 20 --warmup 5 $X --no-batched"
 S="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 $X --no-batched"
 T="python3 $ROOT/bench.py --steps 2 --warmup 1 --prewarm-ms 0 --batched-steps 2 $X"
-R="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-fp32 --no-bwk --no-batched --no-host-call --no-shared-block --no-fresh-uw"
+R="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-fp32 --no-bwk --no-batched --no-host-call --no-shared-block --no-fresh-uw --no-x2"
 U="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-fp32 --no-bwk --no-batched --no-host-call --no-shared-block --no-reflayout"
 N="python3 $ROOT/tools/nlk_bench.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o run -- $B > $OUT/kt.log 2>&1
