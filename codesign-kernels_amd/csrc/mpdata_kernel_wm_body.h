@@ -191,16 +191,16 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   static_assert(TPW == 1 || (TPW == 2 && !STREAM), "two tracers per wave: batch form only");
   static_assert(!UWREF || (STREAM && TPW == 1), "u, w from the reference layout: one tracer per launch");
   using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
-  // T1X (FAST, fp64, one tracer per wave): the 7-operation extrema and the ring sums of the two-tracer form
+  // T1X (FAST, one tracer per wave; fp64 and the two-instances-per-lane fp32 form): the 7-operation extrema and the ring sums of the two-tracer form
   // (XNEW, XSUM below: 6 operations per column fewer) in 128 VGPRs.  The registers come from: rho folded into
   // the limiter's reciprocal, one flux accumulator, ONE ring value dW/adz - U per column instead of U and dW
-  // (ESUM), the flux position formed again behind the march.  +1 % on the headline; in the u, w-ring form it
+  // (ESUM), the flux position formed again behind the march.  +1 % on the headline (and on fp32); in the u, w-ring form it
   // spills (-DMPDWM_UW_X: -7 %), and in the two-tracer form ESUM alone costs 1 % (scheduling): both left as they were.
 #if !defined(MPDWM_NO_T1X) && defined(MPDATA_FAST_DIV) && !defined(MPDWM_EXTREMA_OLD)
 #ifdef MPDWM_UW_X
-  constexpr bool T1X = TPW == 1 && std::is_same<R, double>::value;
+  constexpr bool T1X = TPW == 1;
 #else
-  constexpr bool T1X = TPW == 1 && !UWREF && std::is_same<R, double>::value;
+  constexpr bool T1X = TPW == 1 && !UWREF;
 #endif
 #else
   constexpr bool T1X = false;
