@@ -38,11 +38,14 @@ struct BwkArgs {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 // qtens is read once and written once: BWK_NT marks the stream non-temporal
-#ifdef BWK_NT
+#if defined(BWK_NT) || defined(BWK_NT_LD)
 #define BWK_LOAD(p) __builtin_nontemporal_load(reinterpret_cast<const d4*>(p))
-#define BWK_STORE(p, v) __builtin_nontemporal_store((v), reinterpret_cast<d4*>(p))
 #else
 #define BWK_LOAD(p) (*reinterpret_cast<const d4*>(p))
+#endif
+#if defined(BWK_NT) || defined(BWK_NT_ST)
+#define BWK_STORE(p, v) __builtin_nontemporal_store((v), reinterpret_cast<d4*>(p))
+#else
 #define BWK_STORE(p, v) (*reinterpret_cast<d4*>(p) = (v))
 #endif
 
