@@ -223,6 +223,10 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   // count, measured 1 % faster -- the chip runs at the clock its power draw leaves it, and these are cheaper operations)
   // (the select form in the two-tracer kernel: 7 operations per pair instead of 6, no difference measured)
   constexpr bool SELUP = TPW == 1;
+  // fp64: same operations in an order with shorter dependency chains (the extrema as a tree with the shifted
+  // values last; FAST: the limiter denominators' horizontal part formed ahead of W2u, one multiplication behind
+  // the reciprocal instead of two): +0.5 % on the headline.  (The fp32 forms spill with it.)
+  constexpr bool CHAIN = std::is_same<R, double>::value;
   constexpr int SLP = T::SLP, RB = (int)sizeof(R);
   __shared__ R lds[T::LDS_ELEMS];
 
@@ -640,8 +644,13 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         // 7 operations per column instead of 9, each for max and min.  PMX / PMN carry A, MX0 / MN0 carry P.
         G1mx = dmax(F0p, f1_1);
         G1mn = dmin(F0p, f1_1);
-        MX0_1 = dmax(dmax(dmax(S.PMX[C1], F1D_1), F1U_1), G1mx);   // P of column q-1
-        MN0_1 = dmin(dmin(dmin(S.PMN[C1], F1D_1), F1U_1), G1mn);
+        if constexpr (CHAIN) {   // as a tree: the shifted values arrive last
+          MX0_1 = dmax(dmax(S.PMX[C1], G1mx), dmax(F1D_1, F1U_1));   // P of column q-1
+          MN0_1 = dmin(dmin(S.PMN[C1], G1mn), dmin(F1D_1, F1U_1));
+        } else {
+          MX0_1 = dmax(dmax(dmax(S.PMX[C1], F1D_1), F1U_1), G1mx);
+          MN0_1 = dmin(dmin(dmin(S.PMN[C1], F1D_1), F1U_1), G1mn);
+        }
         }
         // the last two halo columns (nx+1, nx+2) keep this first-pass value (:557) and no later
         // step finishes them: store them now (their input values are already in the LDS ring)
@@ -770,16 +779,30 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         // :606-609
         W2p = pp(W2_2);
         W2n = pn(W2_2);
-        const V den_mx = U2n_1 + S.U2P[C2] + IADZ * (pn(W2u) + W2p) + EPS_D;
-        const V den_mn = U2p_1 + S.U2N[C2] + IADZ * (pp(W2u) + W2n) + EPS_D;
+        V den_mx, den_mn;
+#ifdef MPDATA_FAST_DIV
+        if constexpr (CHAIN) {   // (the horizontal part does not wait for W2u)
+          den_mx = IADZ * (pn(W2u) + W2p) + ((U2n_1 + S.U2P[C2]) + EPS_D);
+          den_mn = IADZ * (pp(W2u) + W2n) + ((U2p_1 + S.U2N[C2]) + EPS_D);
+        } else
+#endif
+        {
+          den_mx = U2n_1 + S.U2P[C2] + IADZ * (pn(W2u) + W2p) + EPS_D;
+          den_mn = U2p_1 + S.U2N[C2] + IADZ * (pp(W2u) + W2n) + EPS_D;
+        }
 #ifdef MPDATA_FAST_DIV
         {  // one reciprocal for both ratios (both denominators >= eps > 0, finite)
           const V dd2 = den_mx * den_mn;
           V r;
           if constexpr (T1X) r = recip_nr(dd2 * IRHO);   // (no rho register)
           else r = RHO * recip_nr(dd2);   // (rho once for both ratios)
-          MXN_2 = (mx1 - S.F1[C2]) * (den_mn * r);
-          MNN_2 = (S.F1[C2] - mn1) * (den_mx * r);
+          if constexpr (CHAIN) {   // (one multiplication behind the reciprocal instead of two)
+            MXN_2 = ((mx1 - S.F1[C2]) * den_mn) * r;
+            MNN_2 = ((S.F1[C2] - mn1) * den_mx) * r;
+          } else {
+            MXN_2 = (mx1 - S.F1[C2]) * (den_mn * r);
+            MNN_2 = (S.F1[C2] - mn1) * (den_mx * r);
+          }
         }
 #else
         MXN_2 = RHO * (mx1 - S.F1[C2]) / den_mx;
