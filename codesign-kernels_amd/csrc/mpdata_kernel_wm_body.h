@@ -205,19 +205,26 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #else
   constexpr bool T1X = false;
 #endif
+  // The u, w-ring form (FAST) takes what fits of it: the merged ring value, the folded rho and the flux position make
+  // room for the 7-operation extrema, not for the ring sums (they spill inside the march: -8 %).  +0.5 ... 0.9 %.
+#if defined(MPDATA_FAST_DIV) && !defined(MPDWM_NO_T1X) && !defined(MPDWM_EXTREMA_OLD)
+  constexpr bool UWX2 = UWREF && !T1X;
+#else
+  constexpr bool UWX2 = false;
+#endif
 #ifdef MPDWM_EXTREMA_OLD
   constexpr bool XNEW = false;
 #else
-  constexpr bool XNEW = TPW == 2 || T1X;   // the 7-operation extrema (stage A below): where the registers allow it
+  constexpr bool XNEW = TPW == 2 || T1X || UWX2;   // the 7-operation extrema (stage A below): where the registers allow it
 #endif
   // FAST, two tracers per wave (the VALU- / power-bound form): three operations per tracer and column fewer
   // by carrying sums in the rings and sharing the velocity parts of the upwind fluxes (below: XSUM)
 #if defined(MPDATA_FAST_DIV) && !defined(MPDWM_NO_XSUM)
-  constexpr bool XSUM = XNEW;
+  constexpr bool XSUM = XNEW && !UWX2;
 #else
   constexpr bool XSUM = false;
 #endif
-  constexpr bool ESUM = T1X;
+  constexpr bool ESUM = T1X || UWX2;
   // the upwind fluxes (:532, :537): two tracers per wave share the velocity parts max(0,u), min(0,u) (a multiply and
   // an FMA per tracer); one tracer per wave takes the select form (compare, two 32-bit selects, multiply: the same
   // count, measured 1 % faster -- the chip runs at the clock its power draw leaves it, and these are cheaper operations)
@@ -794,7 +801,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         {  // one reciprocal for both ratios (both denominators >= eps > 0, finite)
           const V dd2 = den_mx * den_mn;
           V r;
-          if constexpr (T1X) r = recip_nr(dd2 * IRHO);   // (no rho register)
+          if constexpr (T1X || ESUM) r = recip_nr(dd2 * IRHO);   // (no rho register)
           else r = RHO * recip_nr(dd2);   // (rho once for both ratios)
           if constexpr (CHAIN) {   // (one multiplication behind the reciprocal instead of two)
             MXN_2 = ((mx1 - S.F1[C2]) * den_mn) * r;
@@ -976,7 +983,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     const V fl = (UWREF || T1X) ? S1 : S1 + S3;
     int posf = pos;
     bool okf = lvl_ok;
-    if constexpr (T1X) {   // the lane's element, formed again behind the march: no register carries it through
+    if constexpr (T1X || UWX2) {   // the lane's element, formed again behind the march: no register carries it through
       unsigned z;
       asm volatile("s_mov_b32 %0, 0" : "=s"(z));
       const int l2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
