@@ -11,6 +11,7 @@
 // import / export of a plan -- outside the timed region, like the reference's
 // `!$acc update device / host` (:107, :241).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "mpdata_layout.h"
 
@@ -168,8 +169,10 @@ __global__ void __launch_bounds__(256) wm_convert_cols_kernel(const MpdataLayout
     if (cs + 1 < j.ncols) fetch();
 #pragma unroll
     for (int e = 0; e < NPT; ++e) {
+      // (streaming hint on the reference-side row stores of an export: +9 %; on the loads, or on the 8-byte stores
+      //  of an import, it costs 15-35 %)
       if (TO_PRIVATE) { if (pl[e] >= 0) *pp[e] = tb[pl[e]]; pp[e] += pstep[e]; }
-      else { if (rl[e] >= 0) *rp[e] = tb[rl[e]]; rp[e] += rcol; }
+      else { if (rl[e] >= 0) __builtin_nontemporal_store(tb[rl[e]], rp[e]); rp[e] += rcol; }
     }
   }
 }
@@ -192,7 +195,9 @@ hipError_t mpdata_layout_convert_cols(const MpdataLayoutJob* jobs, int nj, bool 
   if (nj == 1) js.j[1] = js.j[0];
   const int nlev = jobs[0].nlev;
   // instances per workgroup: 8 elements per thread and column
-  const int ti = nlev * 64 <= 2048 ? 64 : 32;
+  // (an export is 7 % faster with twice as many, half as wide workgroups; an import is not)
+  static const int ti_env = [] { const char* v = getenv("MPDATA_CONV_TI"); return v ? atoi(v) : 0; }();   // (experiments: 32 / 64)
+  const int ti = ti_env == 32 || (ti_env == 0 && !to_private) ? 32 : (nlev * 64 <= 2048 ? 64 : 32);
   const dim3 grid((unsigned)((nc + ti - 1) / ti), 1, (unsigned)(nj * js.ntr_max)), block(256);
   const size_t lds = (size_t)2 * nlev * (ti + 1) * 8;
   if (ti == 64) {
