@@ -144,16 +144,24 @@ __global__ void __launch_bounds__(256) wm_convert_cols_kernel(const MpdataLayout
     pstep[e] = pmain[e] ? j.main_e : rem_e;
     pp[e] = prv + po[e] + (long long)j.prv_col0 * pstep[e];
   }
-  R v[NPT];
-  auto fetch = [&]() {   // the column the pointers stand on; then on to the next
+  // MPD_CONV_DEPTH columns in flight: the fetch of column c + DEPTH goes out before column c + 1 is waited for.
+#ifndef MPD_CONV_DEPTH
+#define MPD_CONV_DEPTH 2
+#endif
+  constexpr int DEPTH = MPD_CONV_DEPTH;
+  R vs[DEPTH][NPT];
+  auto fetch = [&](R (&v)[NPT]) {   // the column the source pointers stand on; then on to the next
 #pragma unroll
     for (int e = 0; e < NPT; ++e) {
-      if (TO_PRIVATE) { if (rl[e] >= 0) v[e] = *rp[e]; }
-      else if (pl[e] >= 0) v[e] = *pp[e];
+      if (TO_PRIVATE) { if (rl[e] >= 0) v[e] = *rp[e]; rp[e] += rcol; }
+      else { if (pl[e] >= 0) v[e] = *pp[e]; pp[e] += pstep[e]; }
     }
   };
-  fetch();
-  for (int cs = 0; cs < j.ncols; ++cs) {
+  // destination pointers of their own (the source pointers run two columns ahead)
+  R* dp[NPT];
+#pragma unroll
+  for (int e = 0; e < NPT; ++e) dp[e] = TO_PRIVATE ? pp[e] : rp[e];
+  auto column = [&](R (&v)[NPT], const int cs) {
     R* tb = tile + (cs & 1) * tsz;
 #pragma unroll
     for (int e = 0; e < NPT; ++e) {
@@ -161,19 +169,22 @@ __global__ void __launch_bounds__(256) wm_convert_cols_kernel(const MpdataLayout
       if (l >= 0) tb[l] = v[e];
     }
     __syncthreads();   // (two buffers: the previous column's readers are past the barrier of this one's predecessor)
-    // the source pointers move on and the next column is fetched while this one goes out of the tile
-#pragma unroll
-    for (int e = 0; e < NPT; ++e) {
-      if (TO_PRIVATE) rp[e] += rcol; else pp[e] += pstep[e];
-    }
-    if (cs + 1 < j.ncols) fetch();
+    if (cs + DEPTH < j.ncols) fetch(v);
 #pragma unroll
     for (int e = 0; e < NPT; ++e) {
       // (streaming hint on the reference-side row stores of an export: +9 %; on the loads, or on the 8-byte stores
       //  of an import, it costs 15-35 %)
-      if (TO_PRIVATE) { if (pl[e] >= 0) *pp[e] = tb[pl[e]]; pp[e] += pstep[e]; }
-      else { if (rl[e] >= 0) __builtin_nontemporal_store(tb[rl[e]], rp[e]); rp[e] += rcol; }
+      if (TO_PRIVATE) { if (pl[e] >= 0) *dp[e] = tb[pl[e]]; dp[e] += pstep[e]; }
+      else { if (rl[e] >= 0) __builtin_nontemporal_store(tb[rl[e]], dp[e]); dp[e] += rcol; }
     }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < j.ncols) fetch(vs[d]);
+  for (int cs = 0; cs < j.ncols; cs += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (cs + d < j.ncols) column(vs[d], cs + d);
   }
 }
 
