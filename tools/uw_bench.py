@@ -20,6 +20,7 @@ ap.add_argument("--nz", type=int, default=28)
 ap.add_argument("--no-plan", action="store_true")
 ap.add_argument("--no-uw", action="store_true")
 ap.add_argument("--no-conv", action="store_true")
+ap.add_argument("--batch", type=int, default=0, help="also: run_uw on plans of this many tracers (fresh u, w per step)")
 a = ap.parse_args()
 M.set_variant(M.VARIANT_FAST if a.variant == "fast" else M.VARIANT_EXACT)
 dev = torch.device("cuda", 0)
@@ -76,3 +77,23 @@ if not a.no_conv:
     print(f"export f        : {ms:.4f} ms  {2 * nb / ms / 1e6:.0f} GB/s")
 for p, _, _ in sets:
     p.close()
+if a.batch > 1:   # tracer batches on fresh reference-layout u, w: MPDATA_RUN_UW=import selects the conversion path
+    T = a.batch
+    nb = max(3, min(8, int(torch.cuda.mem_get_info()[0] * 0.5 // (ftmp.numel() * 8 * T))))
+    plans = []
+    for s_ in range(nb):
+        p = M.Plan(ncrms, nx, nz, T)
+        p.set_stream(); p.set_timing(False)
+        p.import_device(None, sets[s_ % n][1], sets[s_ % n][2], small["rho"], small["rhow"], small["adz"], None)
+        for t in range(T):
+            M.fill_synthetic(ftmp, "f", 300 + s_ * T + t, 1)
+            p.import_device(ftmp, flux=small["flux"], first_tracer=t)
+        plans.append(p)
+    torch.cuda.synchronize()
+    ms = timed(lambda i: plans[i % nb].run_uw(sets[(i + 1) % n][1], sets[(i + 1) % n][2]), 12, 4)
+    abT = M.algorithmic_bytes(ncrms, nx, nz, T)
+    print(f"run_uw T={T} cold : {ms:.4f} ms  {cells * T / ms / 1e6:.1f} Gcu/s  frac {abT / ms / 1e6 / 8000:.4f}  ({os.environ.get('MPDATA_RUN_UW', 'direct')})")
+    ms = timed(lambda i: plans[i % nb].run(), 12, 4)
+    print(f"plan   T={T} cold : {ms:.4f} ms  {cells * T / ms / 1e6:.1f} Gcu/s  frac {abT / ms / 1e6 / 8000:.4f}")
+    for p in plans:
+        p.close()
