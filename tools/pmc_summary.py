@@ -69,9 +69,30 @@ def trace(passname, kernel, out):
     with open(os.path.join(dst, out)) as fh:
         for row in csv.DictReader(fh):
             if is_k(kernel, row["Name"]):
-                return {"name": row["Name"], "avg_ns": float(row["AverageNs"]), "calls": int(row["Calls"]),
-                        "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"])}
+                r = {"name": row["Name"], "avg_ns": float(row["AverageNs"]), "calls": int(row["Calls"]),
+                     "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"])}
+                r.update(per_dispatch(passname, kernel))
+                return r
     return None
+
+
+def per_dispatch(passname, kernel):
+    """median and the mean of the LAST 40 dispatches of `kernel` in a kernel-trace pass (the bench process starts
+    from an idle chip: its first launches run 10 % faster than the steady state the timed region sees, and the
+    average over all dispatches contains them)"""
+    if not have(f"{passname}/**/*_kernel_trace.csv"):
+        return {}
+    d = []
+    with open(one(f"{passname}/**/*_kernel_trace.csv")) as fh:
+        for row in csv.DictReader(fh):
+            if is_k(kernel, row["Kernel_Name"]):
+                d.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    d = [x[1] for x in sorted(d)]
+    if len(d) < 8:
+        return {}
+    last = d[-40:]
+    return {"median_ns": float(sorted(d)[len(d) // 2]), "mean_last40_ns": sum(last) / len(last),
+            "mean_first5_ns": sum(d[:5]) / 5.0}
 
 
 def alg_bytes(t):
@@ -112,7 +133,11 @@ summary["t1_wavemajor"] = {
     "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg_bytes(1),
     "ratio_traffic_over_algorithmic": (rd + wr) / alg_bytes(1),
     "algorithmic_GBs_at_kernel_trace_avg": alg_bytes(1) / kt["avg_ns"],
-    "frac_of_8TBs": alg_bytes(1) / kt["avg_ns"] / 8000.0,
+    # cold = the last 40 dispatches (the warm-up, timed and per-launch passes of bench.py: a field set of its own per
+    # launch); the average over ALL dispatches contains the pre-warm launches, which re-run ONE field set and find
+    # part of it in the Infinity Cache
+    "frac_of_8TBs": alg_bytes(1) / kt.get("mean_last40_ns", kt["avg_ns"]) / 8000.0,
+    "frac_of_8TBs_all_dispatches": alg_bytes(1) / kt["avg_ns"] / 8000.0,
     "sq_per_wave": {c: v / waves for c, v in sq.items() if c != "SQ_WAVES"}, "waves": waves,
     "valu_instructions_per_wave": sq["SQ_INSTS_VALU"] / waves}
 traffic[f"fast_ncrms{NCRMS}_nx{NX}_nz{NZ}_t1_wm"] = {"hbm_bytes_per_launch": rd + wr,
