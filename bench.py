@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--no-fresh-uw", action="store_true", help="skip the step_with_fresh_uw side block")
     ap.add_argument("--no-x2", action="store_true", help="skip the twice_the_instances side block")
     ap.add_argument("--no-shared-block", action="store_true", help="skip the shared-u,w side block")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the headline block and the cpu_baseline only: no side block runs")
     ap.add_argument("--layout", choices=["wavemajor", "reference"], default="wavemajor",
                     help="device layout of the plans the headline runs on (include/mpdata_hip.h section 3)")
     return ap.parse_args()
@@ -339,24 +341,50 @@ def free_bytes(torch):
     return torch.cuda.mem_get_info()[0]
 
 
-def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=None):
+class InjectedFailure(RuntimeError):
+    """MPDATA_BENCH_FAIL=<block>:<rank>[:mid][,...] (tests/test_bench_rehearsal.py): the named block raises
+    on that rank, at its start or in the middle of its timed loop"""
+
+
+FAIL_SPEC = os.environ.get("MPDATA_BENCH_FAIL", "")
+CURRENT_BLOCK = [None]   # name of the side block that is running (failure injection)
+
+
+def inject_failure(name, phase):
+    for spec in FAIL_SPEC.split(","):
+        parts = spec.split(":")
+        if len(parts) >= 2 and parts[0] == name and int(parts[1]) == int(os.environ.get("RANK", "0")) and \
+                (parts[2] if len(parts) > 2 else "start") == phase:
+            raise InjectedFailure(f"injected failure in block {name!r} ({phase}) on rank {parts[1]}")
+
+
+def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=None, collective=True):
     """W untimed warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier +
     synchronize, with ONE pair of HIP events on the launch stream around the K launches (kernel
     time per step = elapsed / K: the kernels run back to back, nothing else is on the stream; an
     event pair per step would put two marker packets between any two kernels and is kept out of
     the timed region).  A second, untimed pass with an event pair per step gives the spread.
-    Returns (max-over-ranks wall seconds, [mean kernel ms per step] + per-step samples)."""
+    Returns (max-over-ranks wall seconds, [mean kernel ms per step] + per-step samples).
+
+    collective = False (every side block): NO barrier and no all-reduce in here -- the rank times
+    its own K steps, and main() takes the maximum over the ranks in the one all-reduce that every
+    rank reaches whether its block raised or not (a rank that raises between two barriers would
+    leave the others waiting until the driver's timeout)."""
     if PREWARM_MS > 0 and prewarm_launch is not None:   # GPU wake-up (clock / power-state ramp)
         t_end = time.perf_counter() + PREWARM_MS * 1e-3
+        n = 0
         while time.perf_counter() < t_end:
             for _ in range(8):
-                prewarm_launch()
+                prewarm_launch(n)
+                n += 1
             torch.cuda.synchronize()
     for i in range(warmup):
         launch(-1 - i)
+    if CURRENT_BLOCK[0] is not None:
+        inject_failure(CURRENT_BLOCK[0], "mid")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 and collective:
         dist_mod.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -365,7 +393,7 @@ def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=Non
         launch(i)
     e1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 and collective:
         dist_mod.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -379,7 +407,7 @@ def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=Non
         ev[i][1].record()
     torch.cuda.synchronize()
     samples = [a.elapsed_time(b) for a, b in ev]
-    if world > 1:
+    if world > 1 and collective:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist_mod.get_backend() == "nccl" else "cpu")
         dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
         dt = float(t.item())
@@ -408,10 +436,9 @@ def _ev_ms(torch, fn, reps=1):
     return e0.elapsed_time(e1) / reps
 
 
-def bench_plan(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup,
-               dist_law, np_dtype, tdt, mem_frac=0.55, shared_uw=False):
-    """The hot path behind the plan API (device state in the library's own layout,
-    include/mpdata_hip.h section 3): one step = one run of `ntr` tracers on a field set of its own.
+class PlanSets:
+    """The field sets one block steps through behind the plan API (device state in the library's own
+    layout, include/mpdata_hip.h section 3): one step = one run of `ntr` tracers on a field set of its own.
 
     shared_uw = False (the headline): every field set is a PLAN OF ITS OWN with its own f AND its own
     u, w, rho, rhow, adz (same input law, per-set seed), so that no timed launch re-reads a byte the
@@ -419,100 +446,150 @@ def bench_plan(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, s
     :237-239).  shared_uw = True: one plan, the field sets are tracers of it and share u, w (what
     consecutive tracers of one CRM step look like; 1.05 of the 2.14 GB of a launch are then the
     previous launch's bytes).  As many sets as the steps need are created if they fit in `mem_frac`
-    of the free memory (at most MAX_COLD_SETS distinct ones); otherwise the timed steps cycle."""
-    eb = 8 if tdt == torch.float64 else 4
-    f_bytes = n_loc * (nx + 6) * (nz - 1) * eb * ntr
-    uw_bytes = n_loc * ((nx + 5) * (nz - 1) + (nx + 4) * nz) * eb
-    set_bytes = f_bytes + (0 if shared_uw else int(1.1 * uw_bytes))
-    want = steps + min(warmup, N_SCRATCH)
-    if not shared_uw:
-        want = min(want, MAX_COLD_SETS)
-    nset = int(max(2, min(want, (free_bytes(torch) * mem_frac) // set_bytes)))
-    ftmp = torch.empty(shape_f, dtype=tdt, device=dev)
-    conv = {}
-    if shared_uw:
-        plan = M.Plan(n_loc, nx, nz, nset * ntr, dtype=np_dtype)
-        plan.set_stream()
-        plan.set_timing(False)   # (timed_loop brackets the K launches with ONE event pair)
-        plan.import_device(None, shared["u"], shared["w"], shared["rho"], shared["rhow"], shared["adz"], None)
-        for t in range(nset * ntr):     # per-tracer / per-set seeds: distinct data, same law
-            M.fill_synthetic(ftmp, "f", 100 + t, dist_law, ncrms_global=n_glob, sl0=sl0)
-            plan.import_device(ftmp, flux=shared["flux"], first_tracer=t)
-        plans = [plan]
-        run = lambda s: plan.run(s * ntr, ntr)
-    else:
-        plans = []
-        tmp = {k: torch.empty_like(shared[k]) for k in ("u", "w", "rho", "rhow", "adz")}
-        for sset in range(nset):
-            pl = M.Plan(n_loc, nx, nz, ntr, dtype=np_dtype)
-            pl.set_stream()
-            pl.set_timing(False)   # (timed_loop brackets the K launches with ONE event pair)
-            for k in tmp:
-                M.fill_synthetic(tmp[k], k, 100 + 7919 * (sset + 1), dist_law, ncrms_global=n_glob, sl0=sl0)
-            if sset == 0:   # layout-entry cost, measured on its own (no fill inside): u + w, then one tracer of f
+    of the free memory (at most MAX_COLD_SETS distinct ones); otherwise the timed steps cycle.
+
+    Creating the sets (the allocations: the likeliest thing to fail) is separate from timing them, so
+    that the ranks of a multi-GPU run can agree that every one of them got this far before the first
+    barrier of the timed loop."""
+
+    def __init__(self, M, torch, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup,
+                 dist_law, np_dtype, tdt, mem_frac=0.55, shared_uw=False):
+        self.plans = []
+        try:
+            self._setup(M, torch, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup, dist_law,
+                        np_dtype, tdt, mem_frac, shared_uw)
+        except BaseException:
+            self.close(torch)
+            raise
+
+    def _setup(self, M, torch, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup, dist_law,
+               np_dtype, tdt, mem_frac, shared_uw):
+        eb = 8 if tdt == torch.float64 else 4
+        f_bytes = n_loc * (nx + 6) * (nz - 1) * eb * ntr
+        uw_bytes = n_loc * ((nx + 5) * (nz - 1) + (nx + 4) * nz) * eb
+        set_bytes = f_bytes + (0 if shared_uw else int(1.1 * uw_bytes))
+        want = steps + min(warmup, N_SCRATCH)
+        if not shared_uw:
+            want = min(want, MAX_COLD_SETS)
+        nset = int(max(2, min(want, (free_bytes(torch) * mem_frac) // set_bytes)))
+        ftmp = torch.empty(shape_f, dtype=tdt, device=dev)
+        conv = {}
+        plans = self.plans
+        if shared_uw:
+            plan = M.Plan(n_loc, nx, nz, nset * ntr, dtype=np_dtype)
+            plans.append(plan)
+            plan.set_stream()
+            plan.set_timing(False)   # (timed_loop brackets the K launches with ONE event pair)
+            plan.import_device(None, shared["u"], shared["w"], shared["rho"], shared["rhow"], shared["adz"], None)
+            for t in range(nset * ntr):     # per-tracer / per-set seeds: distinct data, same law
+                M.fill_synthetic(ftmp, "f", 100 + t, dist_law, ncrms_global=n_glob, sl0=sl0)
+                plan.import_device(ftmp, flux=shared["flux"], first_tracer=t)
+            run = lambda s: plan.run(s * ntr, ntr)
+        else:
+            tmp = {k: torch.empty_like(shared[k]) for k in ("u", "w", "rho", "rhow", "adz")}
+            for sset in range(nset):
+                pl = M.Plan(n_loc, nx, nz, ntr, dtype=np_dtype)
+                plans.append(pl)
+                pl.set_stream()
+                pl.set_timing(False)   # (timed_loop brackets the K launches with ONE event pair)
+                for k in tmp:
+                    M.fill_synthetic(tmp[k], k, 100 + 7919 * (sset + 1), dist_law, ncrms_global=n_glob, sl0=sl0)
+                if sset == 0:   # layout-entry cost, measured on its own (no fill inside): u + w, then one tracer of f
+                    pl.import_device(None, tmp["u"], tmp["w"], tmp["rho"], tmp["rhow"], tmp["adz"], None)
+                    conv["import_ms_u_and_w"] = _ev_ms(torch, lambda: pl.import_device(None, tmp["u"], tmp["w"]), 3)
                 pl.import_device(None, tmp["u"], tmp["w"], tmp["rho"], tmp["rhow"], tmp["adz"], None)
-                conv["import_ms_u_and_w"] = _ev_ms(torch, lambda: pl.import_device(None, tmp["u"], tmp["w"]), 3)
-            pl.import_device(None, tmp["u"], tmp["w"], tmp["rho"], tmp["rhow"], tmp["adz"], None)
-            for t in range(ntr):
-                M.fill_synthetic(ftmp, "f", 100 + sset * ntr + t, dist_law, ncrms_global=n_glob, sl0=sl0)
-                pl.import_device(ftmp, flux=shared["flux"], first_tracer=t)
-            if sset == 0:
-                conv["import_ms_f_per_tracer"] = _ev_ms(torch, lambda: pl.import_device(ftmp, first_tracer=ntr - 1), 3)
-                conv["export_ms_f_per_tracer"] = _ev_ms(torch, lambda: pl.export_device(ftmp, first_tracer=ntr - 1), 3)
-                conv["bytes_per_array"] = int(ftmp.numel() * eb)
-                pl.import_device(ftmp, first_tracer=ntr - 1)   # (the export wrote into ftmp: same values back)
-            plans.append(pl)
-        del tmp
-        run = lambda s: plans[s].run()
-    torch.cuda.synchronize()
-    del ftmp
-    nscr = min(max(warmup, 1), N_SCRATCH, nset - 1)
-    ntimed = nset - nscr
+                for t in range(ntr):
+                    M.fill_synthetic(ftmp, "f", 100 + sset * ntr + t, dist_law, ncrms_global=n_glob, sl0=sl0)
+                    pl.import_device(ftmp, flux=shared["flux"], first_tracer=t)
+                if sset == 0:
+                    conv["import_ms_f_per_tracer"] = _ev_ms(torch, lambda: pl.import_device(ftmp, first_tracer=ntr - 1), 3)
+                    conv["export_ms_f_per_tracer"] = _ev_ms(torch, lambda: pl.export_device(ftmp, first_tracer=ntr - 1), 3)
+                    conv["bytes_per_array"] = int(ftmp.numel() * eb)
+                    pl.import_device(ftmp, first_tracer=ntr - 1)   # (the export wrote into ftmp: same values back)
+            del tmp
+            run = lambda s: plans[s].run()
+        torch.cuda.synchronize()
+        del ftmp
+        nscr = min(max(warmup, 1), N_SCRATCH, nset - 1)
+        ntimed = nset - nscr
+        self.run, self.nset, self.nscr, self.ntimed = run, nset, nscr, ntimed
+        self.info = {"layout": "wave-major (plan-private)" if plans[0].layout == M.LAYOUT_WAVEMAJOR else "reference",
+                     "field_sets": ntimed, "steps_per_field_set": -(-steps // ntimed),
+                     "uw_shared_across_steps": bool(shared_uw), "conversion": conv}
 
-    def launch(i):
-        s = (nset - 1 - ((-1 - i) % nscr)) if i < 0 else (i % ntimed)   # warm-up: the scratch sets
-        run(s)
+    def launch(self, i):
+        """i >= 0: timed step i on field set i mod ntimed; i < 0: warm-up step on the scratch sets"""
+        self.run((self.nset - 1 - ((-1 - i) % self.nscr)) if i < 0 else (i % self.ntimed))
 
-    dt, kms = timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=lambda: launch(-1))
-    info = {"layout": "wave-major (plan-private)" if plans[0].layout == M.LAYOUT_WAVEMAJOR else "reference",
-            "field_sets": ntimed, "steps_per_field_set": -(-steps // ntimed), "uw_shared_across_steps": bool(shared_uw),
-            "conversion": conv}
-    for pl in plans:
-        pl.close()
-    torch.cuda.empty_cache()
-    return dt, kms, info
+    def prewarm(self, n):
+        """GPU wake-up launch number n: CYCLES through the scratch sets, so that consecutive wake-up
+        launches work on different field sets as the timed ones do (1.6 GB each: nothing of a launch is
+        left in the 256-MB Infinity Cache when its set comes round again) -- every dispatch of a
+        profiled run is then a cold one and the plain average of its kernel trace is the cold figure"""
+        self.launch(-1 - (n % self.nscr))
+
+    def close(self, torch):
+        for pl in self.plans:
+            try:
+                pl.close()
+            except Exception:
+                pass
+        self.plans = []
+        try:
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
+
+
+def bench_plan(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup,
+               dist_law, np_dtype, tdt, mem_frac=0.55, shared_uw=False, collective=False):
+    """field sets + timed loop of a SIDE block (no collective inside: see timed_loop)"""
+    sets = PlanSets(M, torch, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup, dist_law, np_dtype,
+                    tdt, mem_frac, shared_uw)
+    try:
+        dt, kms = timed_loop(torch, dist_mod, world, sets.launch, steps, warmup, prewarm_launch=sets.prewarm,
+                             collective=collective)
+        return dt, kms, sets.info
+    finally:
+        sets.close(torch)
 
 
 def bench_fresh_uw(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glob, sl0, nx, nz, steps, warmup,
                    dist_law, np_dtype, tdt, nsets=16):
     """One step = mpdata_plan_run_uw(plan, u, w) with u, w in the REFERENCE layout on the device,
     distinct arrays for consecutive steps (a set = a plan with its own f + its own reference-layout
-    u, w: 2.7 GB, the steps cycle through `nsets` of them)."""
+    u, w: 2.7 GB, the steps cycle through `nsets` of them).  Side block: no collective inside."""
     sets = []
-    ftmp = torch.empty(shape_f, dtype=tdt, device=dev)
-    for s_ in range(nsets):
-        pl = M.Plan(n_loc, nx, nz, 1, dtype=np_dtype)
-        pl.set_stream()
-        pl.set_timing(False)
-        u = torch.empty_like(shared["u"]); w = torch.empty_like(shared["w"])
-        M.fill_synthetic(u, "u", 500 + 31 * s_, dist_law, ncrms_global=n_glob, sl0=sl0)
-        M.fill_synthetic(w, "w", 500 + 31 * s_, dist_law, ncrms_global=n_glob, sl0=sl0)
-        M.fill_synthetic(ftmp, "f", 500 + s_, dist_law, ncrms_global=n_glob, sl0=sl0)
-        pl.import_device(ftmp, u, w, shared["rho"], shared["rhow"], shared["adz"], shared["flux"])
-        sets.append((pl, u, w))
-    del ftmp
-    nscr = 2
+    try:
+        ftmp = torch.empty(shape_f, dtype=tdt, device=dev)
+        for s_ in range(nsets):
+            pl = M.Plan(n_loc, nx, nz, 1, dtype=np_dtype)
+            sets.append((pl, None, None))
+            pl.set_stream()
+            pl.set_timing(False)
+            u = torch.empty_like(shared["u"]); w = torch.empty_like(shared["w"])
+            M.fill_synthetic(u, "u", 500 + 31 * s_, dist_law, ncrms_global=n_glob, sl0=sl0)
+            M.fill_synthetic(w, "w", 500 + 31 * s_, dist_law, ncrms_global=n_glob, sl0=sl0)
+            M.fill_synthetic(ftmp, "f", 500 + s_, dist_law, ncrms_global=n_glob, sl0=sl0)
+            pl.import_device(ftmp, u, w, shared["rho"], shared["rhow"], shared["adz"], shared["flux"])
+            sets[-1] = (pl, u, w)
+        del ftmp
+        nscr = 2
 
-    def launch(i):
-        pl, u, w = sets[(nsets - 1 - ((-1 - i) % nscr)) if i < 0 else (i % (nsets - nscr))]
-        pl.run_uw(u, w)
+        def launch(i):
+            pl, u, w = sets[(nsets - 1 - ((-1 - i) % nscr)) if i < 0 else (i % (nsets - nscr))]
+            pl.run_uw(u, w)
 
-    dt, kms = timed_loop(torch, dist_mod, world, launch, steps, warmup)
-    for pl, _, _ in sets:
-        pl.close()
-    del sets
-    torch.cuda.empty_cache()
-    return dt, kms, nsets - nscr
+        dt, kms = timed_loop(torch, dist_mod, world, launch, steps, warmup, collective=False)
+        return dt, kms, nsets - nscr
+    finally:
+        for pl, _, _ in sets:
+            try:
+                pl.close()
+            except Exception:
+                pass
+        del sets
+        torch.cuda.empty_cache()
 
 
 def kavg(kms):
@@ -605,13 +682,51 @@ def main():
     sh_f1 = M.shapes(n_loc, nx, nz, 1)["f"]
     cells_1 = n_glob * nx * (nz - 1)
 
+    # ---- the ranks' agreement: ONE all-reduce that every rank reaches, whether its block raised or not
+    def agree(failed, dt=0.0):
+        """-> (any rank failed, max over ranks of dt)"""
+        if world == 1:
+            return bool(failed), float(dt)
+        t = torch.tensor([1.0 if failed else 0.0, float(dt)], dtype=torch.float64,
+                         device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t[0].item() > 0), float(t[1].item())
+
+    def emit(obj, code=0):
+        if rank == 0:
+            print(json.dumps(obj), flush=True)
+        if world > 1:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        if code:
+            sys.exit(code)
+
     # ---- headline: configs[2] per GPU through the plan API -----------------------------------
-    dt, kms, info = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, ntr, steps,
-                               warmup, args.dist, npdt, tdt, mem_frac, shared_uw=args.shared_uw)
+    # phase 1, no collective: the field sets (the allocations); the ranks then agree that all of them got
+    # this far BEFORE the first barrier of the timed loop
+    sets, err = None, None
+    try:
+        sets = PlanSets(M, torch, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, ntr, steps, warmup, args.dist, npdt,
+                        tdt, mem_frac, shared_uw=args.shared_uw)
+    except Exception as exc:
+        err = repr(exc)
+    if agree(err is not None)[0]:
+        emit({"metric": "advected cell-updates/sec, MPDATA advect_scalar2D", "value": None, "n_gpus": world,
+              "error": "headline setup failed: " + (err or "on another rank")}, code=1)
+        return
+    # phase 2: W warm-up + K timed steps, barrier + synchronize on both sides, max over ranks
+    try:
+        dt, kms = timed_loop(torch, dist, world, sets.launch, steps, warmup, prewarm_launch=sets.prewarm, collective=True)
+        info = sets.info
+    finally:
+        sets.close(torch)
+    del sets
     value = cells_1 * ntr * steps / dt
     alg_bytes = M.algorithmic_bytes(n_loc, nx, nz, ntr, f32=f32)  # per launch (one GPU)
 
-    result = None
+    result = {}
     if rank == 0:
         key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t{ntr}" + ("_f32" if f32 else "") + \
               ("_wm" if info["layout"].startswith("wave") else "")
@@ -634,6 +749,7 @@ def main():
                                "launch was touched by the previous one)" if not info["uw_shared_across_steps"] else
                                "NO: the field sets share u, w",
                        "prewarm_ms": args.prewarm_ms,
+                       "prewarm": "wake-up launches cycle through the scratch field sets (cold, like the timed ones)",
                        "parallelism": f"ncrms-sharded x{world}, no data-path collective",
                        "ranks_seen": ranks_seen, "devices_seen": devices_seen},
             "roofline": roofline_block(alg_bytes, kms, {
@@ -646,6 +762,42 @@ def main():
                                       "outside the timed region of the headline like the reference's `!$acc update "
                                       "device`, :107; `step_with_fresh_uw` charges it"),
         }
+        # the headline exists: on stderr at once (a later block that takes the process down cannot lose it);
+        # stdout gets the ONE full line at the end
+        print("BENCH_HEADLINE " + json.dumps(result), file=sys.stderr, flush=True)
+
+    # ---- side blocks.  Each one is a closure that does its set-up AND its timing WITHOUT any collective and
+    #      returns (seconds of its K steps on this rank, entry(max seconds over the ranks) -> dict).  An
+    #      exception on any rank becomes {"error": ...} under the block's name; every rank then meets in the
+    #      one all-reduce of side() and goes on to the next block.
+    def side(name, body, rank0_only=False):
+        if args.headline_only:
+            return
+        failed, dt_loc, entry, msg = False, 0.0, None, None
+        CURRENT_BLOCK[0] = name
+        try:
+            if not rank0_only or rank == 0:
+                inject_failure(name, "start")
+                dt_loc, entry = body()
+        except Exception as exc:
+            failed, msg = True, repr(exc)
+        CURRENT_BLOCK[0] = None
+        try:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            failed, msg = True, msg or repr(exc)
+        any_failed, dt_max = (failed, dt_loc) if rank0_only else agree(failed, dt_loc)
+        if rank == 0:
+            if any_failed:
+                result[name] = {"error": msg or "the block failed on another rank"}
+            else:
+                try:
+                    result[name] = entry(dt_max)
+                except Exception as exc:
+                    result[name] = {"error": repr(exc)}
+
+    def ceilings():   # measured ceilings of this box, into the headline's roofline object
         try:
             result["roofline"]["measured_copy_GBs"] = copy_ceiling(torch, dev)
         except Exception:
@@ -658,60 +810,59 @@ def main():
         except Exception:
             result["roofline"]["measured_stream_3r1w_GBs"] = None
 
-    # ---- side block: the round-2 protocol (ONE plan, the field sets share u, w, serpentine tile
-    #      order on): what consecutive tracers of one CRM step get ------------------------------
-    if not args.no_shared_block and not args.shared_uw and ntr == 1:
+    # the round-2 protocol (ONE plan, the field sets share u, w, serpentine tile order on): what consecutive
+    # tracers of one CRM step get
+    def b_shared():
         M.set_serpentine(1)
-        ssteps = min(steps, 40)
-        dt6, kms6, info6 = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, 1, ssteps,
+        try:
+            ssteps = min(steps, 40)
+            dt6, kms6, _ = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, 1, ssteps,
                                       SIDE_WARMUP, args.dist, npdt, tdt, 0.3 * mem_frac, shared_uw=True)
-        M.set_serpentine(serp)
-        if rank == 0:
-            result["consecutive_tracers_shared_uw"] = {
-                "workload": "the headline workload with u, w SHARED by all timed launches (one plan, the field sets are "
-                            "its tracers) and the serpentine tile order on: 1.05 of the 2.14 GB of a launch are the "
-                            "previous launch's bytes, part of them still in the Infinity Cache -- NOT a cold call",
-                "value": cells_1 * ssteps / dt6, "unit": "cell-updates/s", "steps": ssteps,
-                "ms_per_step": dt6 / ssteps * 1e3, "roofline": roofline_block(alg_bytes, kms6)}
+        finally:
+            M.set_serpentine(serp)
+        return dt6, lambda dtm: {
+            "workload": "the headline workload with u, w SHARED by all timed launches (one plan, the field sets are "
+                        "its tracers) and the serpentine tile order on: 1.05 of the 2.14 GB of a launch are the "
+                        "previous launch's bytes, part of them still in the Infinity Cache -- NOT a cold call",
+            "value": cells_1 * ssteps / dtm, "unit": "cell-updates/s", "steps": ssteps,
+            "ms_per_step": dtm / ssteps * 1e3, "roofline": roofline_block(alg_bytes, kms6)}
 
-    # ---- side block: one step on FRESH reference-layout u, w (mpdata_plan_run_uw): the layout
-    #      entry of the velocities is inside the timed region, every step ----------------------
-    if not args.no_fresh_uw and ntr == 1 and not f32:
+    # one step on FRESH reference-layout u, w (mpdata_plan_run_uw): the layout entry of the velocities is
+    # inside the timed region, every step
+    def b_fresh_uw():
         fsteps = min(steps, 40)
         dt7, kms7, nfs = bench_fresh_uw(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, fsteps,
                                         SIDE_WARMUP, args.dist, npdt, tdt)
-        if rank == 0:
-            result["step_with_fresh_uw"] = {
-                "workload": f"mpdata_plan_run_uw: f resident in the plan layout, u and w handed over as reference-layout "
-                            f"device arrays EVERY step (distinct arrays per step, {nfs} sets), ncrms={n_loc}/GPU, 1 tracer",
-                "value": cells_1 * fsteps / dt7, "unit": "cell-updates/s", "steps": fsteps,
-                "ms_per_step": dt7 / fsteps * 1e3, "roofline": roofline_block(alg_bytes, kms7)}
+        return dt7, lambda dtm: {
+            "workload": f"mpdata_plan_run_uw: f resident in the plan layout, u and w handed over as reference-layout "
+                        f"device arrays EVERY step (distinct arrays per step, {nfs} sets), ncrms={n_loc}/GPU, 1 tracer",
+            "value": cells_1 * fsteps / dtm, "unit": "cell-updates/s", "steps": fsteps,
+            "ms_per_step": dtm / fsteps * 1e3, "roofline": roofline_block(alg_bytes, kms7)}
 
-    # ---- side block: the headline protocol at TWICE the instances per GPU (north_star: "at ncrms >= 65 536"):
-    #      the fixed part of a launch (ramp, drain of the last wave round, gap to the next launch) halves ----
-    if not args.no_x2 and ntr == 1 and not f32 and not args.shared_uw:
+    # the headline protocol at TWICE the instances per GPU (north_star: "at ncrms >= 65 536"): the fixed part
+    # of a launch (ramp, drain of the last wave round, gap to the next launch) halves
+    def b_x2():
         n2 = 2 * n_loc
         xsteps = min(steps, 16)
         shared2, _, sh2 = make_shared(M, torch, dev, n2, n2 * world, rank * n2, nx, nz, args.dist, tdt)
         dt8, kms8, info8 = bench_plan(M, torch, dist, world, dev, shared2, sh2["f"], n2, n2 * world, rank * n2, nx, nz, 1,
                                       xsteps, SIDE_WARMUP, args.dist, npdt, tdt, 0.5 * mem_frac)
         del shared2
-        torch.cuda.empty_cache()
-        if rank == 0:
-            result["twice_the_instances"] = {
-                "workload": f"the headline protocol (cold: a plan of its own per timed step, {info8['field_sets']} sets) at "
-                            f"ncrms={n2}/GPU nx={nx} nz={nz} fp64, 1 tracer",
-                "value": 2 * cells_1 * xsteps / dt8, "unit": "cell-updates/s", "steps": xsteps,
-                "ms_per_step": dt8 / xsteps * 1e3,
-                "roofline": roofline_block(M.algorithmic_bytes(n2, nx, nz, 1), kms8)}
+        return dt8, lambda dtm: {
+            "workload": f"the headline protocol (cold: a plan of its own per timed step, {info8['field_sets']} sets) at "
+                        f"ncrms={n2}/GPU nx={nx} nz={nz} fp64, 1 tracer",
+            "value": 2 * cells_1 * xsteps / dtm, "unit": "cell-updates/s", "steps": xsteps,
+            "ms_per_step": dtm / xsteps * 1e3,
+            "roofline": roofline_block(M.algorithmic_bytes(n2, nx, nz, 1), kms8)}
 
-    # ---- BASELINE configs[3] / [4]: 25 tracers per instance, every rank ---------------------
-    if not args.no_batched and ntr == 1:
+    # BASELINE configs[3] / [4]: 25 tracers per instance, every rank
+    def b_batched():
         bt = args.batched_tracers
         bsteps, bwarm = min(steps, args.batched_steps), min(warmup, 2)
         dt2, kms2, info2 = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, bt,
                                       bsteps, bwarm, args.dist, npdt, tdt, mem_frac)
-        if rank == 0:
+
+        def entry(dtm):
             ab = M.algorithmic_bytes(n_loc, nx, nz, bt, f32=f32)
             ka = kavg(kms2)
             key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t{bt}" + ("_f32" if f32 else "") + \
@@ -733,17 +884,19 @@ def main():
                 rb["valu_note"] = "VALU instructions per launch (%s, SQ counters of the builder's box) / measured fp64 " \
                                   "VALU issue peak (tools/valu_rate.hip: 33e12 lane-ops/s, at the 2.0 GHz that " \
                                   "microbenchmark sustains; this kernel runs at 1.7-1.85 GHz, power-limited) / kernel time" % vi[1]
-            result["tracer_batched"] = {
+            return {
                 "workload": f"BASELINE.json configs[{3 if world == 1 else 4}]: ncrms={n_loc}/GPU (global {n_glob}), "
                             f"{bt} tracers sharing u,w,rho,rhow,adz, plan API",
-                "value": cells_1 * bt * bsteps / dt2, "unit": "cell-updates/s", "n_gpus": world,
-                "steps": bsteps, "ms_per_step": dt2 / bsteps * 1e3, "field_sets": info2["field_sets"],
+                "value": cells_1 * bt * bsteps / dtm, "unit": "cell-updates/s", "n_gpus": world,
+                "steps": bsteps, "ms_per_step": dtm / bsteps * 1e3, "field_sets": info2["field_sets"],
                 "steps_per_field_set": info2["steps_per_field_set"], "device_layout": info2["layout"],
+                "timing": "max over the ranks of each rank's own K steps (no barrier inside a side block)",
                 "roofline": rb}
+        return dt2, entry
 
-    # ---- side measurement: the reference-layout device call (x-march kernel): what a caller
-    #      gets whose device arrays stay in the reference layout -------------------------------
-    if not args.no_reflayout and ntr == 1:
+    # the reference-layout device call (x-march kernel): what a caller gets whose device arrays stay in the
+    # reference layout
+    def b_reflayout():
         nb = min(steps + N_SCRATCH, 24)
         fs = []
         for b in range(nb):
@@ -755,22 +908,23 @@ def main():
             M.advect_scalar2D(fs[i % nb], shared["u"], shared["w"], shared["rho"], shared["rhow"], shared["flux"], shared["adz"])
 
         rsteps = min(steps, 40)
-        dt4, kms4 = timed_loop(torch, dist, world, launch_ref, rsteps, SIDE_WARMUP)
-        if rank == 0:
+        dt4, kms4 = timed_loop(torch, dist, world, launch_ref, rsteps, SIDE_WARMUP, collective=False)
+        del fs
+
+        def entry(dtm):
             key = f"{args.variant}_ncrms{n_loc}_nx{nx}_nz{nz}_t1" + ("_f32" if f32 else "")
             tr4 = traffic_lookup(key)
-            result["reference_layout_device_call"] = {
+            return {
                 "workload": f"mpdata_advect_scalar2d{'_f32' if f32 else ''}_device on reference-layout device arrays "
                             f"(x-march kernel), ncrms={n_loc}/GPU, 1 tracer",
-                "value": cells_1 * rsteps / dt4, "unit": "cell-updates/s", "steps": rsteps,
-                "ms_per_step": dt4 / rsteps * 1e3,
+                "value": cells_1 * rsteps / dtm, "unit": "cell-updates/s", "steps": rsteps,
+                "ms_per_step": dtm / rsteps * 1e3,
                 "roofline": roofline_block(alg_bytes, kms4, {"traffic": tr4, "traffic_source": None if tr4 is None else
                                                              "profiles/hbm_traffic.json[%s] (recorded profile)" % key})}
-        del fs
-        torch.cuda.empty_cache()
+        return dt4, entry
 
-    # ---- side measurement: the same workload in fp32 (reference precision switch) ------
-    if not args.no_fp32 and not f32 and ntr == 1:
+    # the same workload in fp32 (reference precision switch)
+    def b_fp32():
         sh32, alloc32, _ = make_shared(M, torch, dev, n_loc, n_glob, sl0, nx, nz, args.dist, torch.float32)
         nb = min(steps + N_SCRATCH, 24)
         fs3 = []
@@ -783,79 +937,96 @@ def main():
             M.advect_scalar2D(fs3[i % nb], sh32["u"], sh32["w"], sh32["rho"], sh32["rhow"], sh32["flux"], sh32["adz"])
 
         s3 = min(steps, 40)
-        dt3, kms3 = timed_loop(torch, dist, world, launch32, s3, SIDE_WARMUP)
+        dt3, kms3 = timed_loop(torch, dist, world, launch32, s3, SIDE_WARMUP, collective=False)
         del fs3
         torch.cuda.empty_cache()
         # ... and through an fp32 plan (wave-major layout, two instances per lane)
         dt5, kms5, info5 = bench_plan(M, torch, dist, world, dev, sh32, sh_f1, n_loc, n_glob, sl0, nx, nz, 1, s3,
                                       SIDE_WARMUP, args.dist, np.float32, torch.float32, 0.3 * mem_frac)
-        if rank == 0:
+        del sh32
+
+        def entry(dtm):   # (dtm: the plan loop; the reference-layout loop reports this rank's own time)
             ab = M.algorithmic_bytes(n_loc, nx, nz, 1, f32=True)
-            result["fp32"] = {
+            return {
                 "workload": f"ncrms={n_loc}/GPU nx={nx} nz={nz} fp32, 1 tracer, plan API ({info5['layout']})",
-                "value": cells_1 * s3 / dt5, "unit": "cell-updates/s", "steps": s3,
-                "ms_per_step": dt5 / s3 * 1e3, "roofline": roofline_block(ab, kms5),
+                "value": cells_1 * s3 / dtm, "unit": "cell-updates/s", "steps": s3,
+                "ms_per_step": dtm / s3 * 1e3, "roofline": roofline_block(ab, kms5),
                 "reference_layout_device_call": {
                     "workload": "mpdata_advect_scalar2d_f32_device on reference-layout device arrays (x-march kernel)",
-                    "value": cells_1 * s3 / dt3, "ms_per_step": dt3 / s3 * 1e3, "roofline": roofline_block(ab, kms3)}}
-        del sh32
+                    "value": n_loc * nx * (nz - 1) * s3 / dt3, "ms_per_step": dt3 / s3 * 1e3,
+                    "note": "rank 0's own shard and time", "roofline": roofline_block(ab, kms3)}}
+        return dt5, entry
+
+    # end to end: the drop-in call on HOST arrays, H2D + kernel + D2H -- never `value`; N = 1 only
+    def b_host_call():
+        host = {}
+        for k in ("f", "u", "w", "rho", "rhow", "adz", "flux"):
+            t = alloc(sh[k], k)
+            M.fill_synthetic(t, k, 300, args.dist, ncrms_global=n_glob, sl0=sl0)
+            host[k] = t.cpu().numpy().T   # Fortran order, the reference's shapes (pageable memory)
+            del t
         torch.cuda.empty_cache()
+        ts = []
+        for _ in range(3):   # (the first call also pays for the library's buffers)
+            t0 = time.perf_counter()
+            M.advect_scalar2D_host(host["f"], host["u"], host["w"], host["rho"], host["rhow"], host["flux"], host["adz"])
+            ts.append(time.perf_counter() - t0)
+        del host
+        return min(ts[1:]), lambda dtm: {
+            "workload": f"mpdata_advect_scalar2d on host arrays (pageable), ncrms={n_loc} nx={nx} nz={nz}, 1 tracer: "
+                        "H2D + kernel + D2H, chunked and pipelined (DESIGN.md 5b)",
+            "seconds_first_call": ts[0], "seconds": min(ts[1:]),
+            "value": cells_1 / min(ts[1:]), "unit": "cell-updates/s",
+            "note": "PCIe-inclusive; reported beside the device-resident `value`, never as it"}
 
-    # ---- end to end: the drop-in call on HOST arrays, H2D + kernel + D2H -- never
-    #      `value`; N = 1 only -------------------------------------------------------------------
-    if world == 1 and rank == 0 and not args.no_host_call and not f32 and ntr == 1:
-        try:
-            host = {}
-            for k in ("f", "u", "w", "rho", "rhow", "adz", "flux"):
-                t = alloc(sh[k], k)
-                M.fill_synthetic(t, k, 300, args.dist, ncrms_global=n_glob, sl0=sl0)
-                host[k] = t.cpu().numpy().T   # Fortran order, the reference's shapes (pageable memory)
-                del t
-            torch.cuda.empty_cache()
-            ts = []
-            for _ in range(3):   # (the first call also pays for the library's buffers)
-                t0 = time.perf_counter()
-                M.advect_scalar2D_host(host["f"], host["u"], host["w"], host["rho"], host["rhow"], host["flux"], host["adz"])
-                ts.append(time.perf_counter() - t0)
-            result["end_to_end_host_call"] = {
-                "workload": f"mpdata_advect_scalar2d on host arrays (pageable), ncrms={n_loc} nx={nx} nz={nz}, 1 tracer: "
-                            "H2D + kernel + D2H, chunked and pipelined (DESIGN.md 5b)",
-                "seconds_first_call": ts[0], "seconds": min(ts[1:]),
-                "value": cells_1 / min(ts[1:]), "unit": "cell-updates/s",
-                "note": "PCIe-inclusive; reported beside the device-resident `value`, never as it"}
-            del host
-        except Exception as exc:
-            result["end_to_end_host_call"] = {"error": repr(exc)}
+    # the second / third kernel, rank 0 only
+    def b_bwk():
+        r = bench_bwk(torch, dev, min(steps, 50), SIDE_WARMUP, world == 1 and not args.no_cpu_baseline)
+        return 0.0, lambda dtm: r
 
-    # ---- side measurement: the second / third kernel, rank 0 only ----------
-    if not args.no_bwk and rank == 0 and not f32 and ntr == 1:
-        try:
-            result["biharmonic_wk"] = bench_bwk(torch, dev, min(steps, 50), SIDE_WARMUP,
-                                                world == 1 and not args.no_cpu_baseline)
-        except Exception as exc:   # a side measurement must not take the headline down
-            result["biharmonic_wk"] = {"error": repr(exc)}
-        try:
-            result["high_order_flux"] = bench_nlk(torch, dev, min(steps, 100), SIDE_WARMUP,
-                                                  world == 1 and not args.no_cpu_baseline)
-        except Exception as exc:
-            result["high_order_flux"] = {"error": repr(exc)}
-        torch.cuda.empty_cache()
+    def b_nlk():
+        r = bench_nlk(torch, dev, min(steps, 100), SIDE_WARMUP, world == 1 and not args.no_cpu_baseline)
+        return 0.0, lambda dtm: r
 
-    # ---- N > 1: scatter / gather of a root-resident problem over RCCL (outside any timed
-    #      compute region): ncrms = ncrms_per_gpu * N, one tracer -------------------------------
-    if world > 1 and not args.no_scatter:
-        try:
-            result_sg = bench_scatter_gather(M, torch, dist, world, rank, dev, n_loc, nx, nz)
-            if rank == 0:
-                result["scatter_gather"] = result_sg
-        except Exception as exc:
-            if rank == 0:
-                result["scatter_gather"] = {"error": repr(exc)}
+    # N > 1: scatter / gather of a root-resident problem over RCCL (outside any timed compute region):
+    # ncrms = ncrms_per_gpu * N, one tracer.  It HAS collectives inside and guards them itself (every rank
+    # agrees that the root could allocate before the first send / recv).
+    def b_scatter():
+        r = bench_scatter_gather(M, torch, dist, world, rank, dev, n_loc, nx, nz)
+        return 0.0, lambda dtm: r
 
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(nx, nz)
-        print(json.dumps(result))
+    try:
+        if rank == 0 and not args.headline_only:
+            ceilings()
+        one = ntr == 1
+        if not args.no_shared_block and not args.shared_uw and one:
+            side("consecutive_tracers_shared_uw", b_shared)
+        if not args.no_fresh_uw and one and not f32:
+            side("step_with_fresh_uw", b_fresh_uw)
+        if not args.no_x2 and one and not f32 and not args.shared_uw:
+            side("twice_the_instances", b_x2)
+        if not args.no_batched and one:
+            side("tracer_batched", b_batched)
+        if not args.no_reflayout and one:
+            side("reference_layout_device_call", b_reflayout)
+        if not args.no_fp32 and not f32 and one:
+            side("fp32", b_fp32)
+        if world == 1 and not args.no_host_call and not f32 and one:
+            side("end_to_end_host_call", b_host_call, rank0_only=True)
+        if not args.no_bwk and not f32 and one:
+            side("biharmonic_wk", b_bwk, rank0_only=True)
+            side("high_order_flux", b_nlk, rank0_only=True)
+        if world > 1 and not args.no_scatter:
+            side("scatter_gather", b_scatter)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(nx, nz)
+            except Exception as exc:
+                result["cpu_baseline"] = {"error": repr(exc)}
+    finally:
+        # whatever happened above (an exception outside a block's own handler, Ctrl-C): the line goes out
+        if rank == 0:
+            print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -21,6 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # MPDATA_HIP_LIB: load an alternative build of the library (kernel experiments)
 _LIB_PATH = os.environ.get("MPDATA_HIP_LIB") or os.path.join(HERE, "libmpdata_hip.so")
 VARIANT_EXACT, VARIANT_FAST = 0, 1
+EINVAL, EUNSUPPORTED, ESTATE, ECOMM = -1, -2, -3, -4   # MPDATA_E* of include/mpdata_hip.h
 LAYOUT_REFERENCE, LAYOUT_WAVEMAJOR = 0, 1
 
 _lib = None
@@ -139,6 +140,10 @@ def lib():
         L.mpdata_set_debug_buffer.restype = ci
         L.mpdata_set_debug_buffer.argtypes = [vp]
         L.mpdata_device_count.restype = ci
+        L.mpdata_plan_device_alloc.restype = ci
+        L.mpdata_plan_device_alloc.argtypes = [vp, ctypes.POINTER(vp), i64]
+        L.mpdata_device_free.restype = ci
+        L.mpdata_device_free.argtypes = [vp]
         L.mpdata_algorithmic_bytes.restype = i64
         L.mpdata_algorithmic_bytes.argtypes = [i64, ci, ci, ci]
         L.mpdata_diag_stream_3r1w.restype = ci

@@ -260,6 +260,28 @@ int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u,
   return 0;
 }
 
+// the device a pointer lives on (the current one if HIP does not know the pointer)
+int device_of(const void* p) {
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return cur;
+  }
+  return at.type == hipMemoryTypeDevice ? at.device : cur;
+}
+struct DevGuardP {   // (DevGuard is declared further down, beside the plans)
+  int prev = -1, dev;
+  explicit DevGuardP(int d) : dev(d) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DevGuardP() {
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+  }
+};
+
 template <typename R>
 int fill_device(R* a, int sid, int64_t rows, int64_t ncrms_global, int64_t sl0, int64_t nloc,
                 uint64_t seed, int dist, void* stream) {
@@ -274,6 +296,10 @@ int fill_device(R* a, int sid, int64_t rows, int64_t ncrms_global, int64_t sl0, 
     if (sid == 2 || sid == 3) shift = -0.5;
   }
   const unsigned long long base = seed + (unsigned long long)sid * 0xD1B54A32D192ED03ull;
+  // (a null stream: the array's own device -- the Fortran driver fills arrays on a plan's root GPU)
+  int cur_dev = 0;
+  (void)hipGetDevice(&cur_dev);
+  DevGuardP g(stream ? cur_dev : device_of(a));
   hipLaunchKernelGGL(fill_kernel<R>, dim3(grid_for(rows * nloc, 256)), dim3(256), 0,
                      (hipStream_t)stream, a, base, shift, (long long)rows, (long long)ncrms_global,
                      (long long)sl0, (long long)nloc);
@@ -385,6 +411,7 @@ struct mpdata_plan {
   bool own_stream;
   hipEvent_t ev0, ev1;
   bool uploaded, ran;
+  bool have_u, have_w;   // the plan holds velocities (imported since the last mpdata_plan_run_uw)
   bool timing;     // record the event pair around every run (mpdata_plan_last_kernel_ms); mpdata_plan_set_timing
   unsigned runs;   // launches so far (serpentine tile order)
   mpdata_multi* multi;  // != null: a multi-GPU plan (mpdata_multi.hip); nothing else above is used
@@ -460,8 +487,8 @@ int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, con
   const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   if (p->layout == MPDATA_LAYOUT_REFERENCE) {
     if (f) HIP_TRY(hipMemcpyAsync((char*)p->f + first * f1 * eb, f, f1 * count * eb, kind, p->stream));
-    if (u) HIP_TRY(hipMemcpyAsync(p->u, u, p->sz.u * eb, kind, p->stream));
-    if (w) HIP_TRY(hipMemcpyAsync(p->w, w, p->sz.w * eb, kind, p->stream));
+    if (u) { HIP_TRY(hipMemcpyAsync(p->u, u, p->sz.u * eb, kind, p->stream)); p->have_u = true; }
+    if (w) { HIP_TRY(hipMemcpyAsync(p->w, w, p->sz.w * eb, kind, p->stream)); p->have_w = true; }
     if (rho) HIP_TRY(hipMemcpyAsync(p->rho, rho, p->sz.k * eb, kind, p->stream));
     if (rhow) HIP_TRY(hipMemcpyAsync(p->rhow, rhow, p->sz.kz * eb, kind, p->stream));
     if (adz) HIP_TRY(hipMemcpyAsync(p->adz, adz, p->sz.k * eb, kind, p->stream));
@@ -500,9 +527,10 @@ int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, con
   if (!rc && u && w && dev && !legacy_convert()) {   // u and w of a device import: ONE launch
     const MpdataLayoutJob j2[2] = {wm_job(p, 1, const_cast<void*>(u), 0, 1), wm_job(p, 2, const_cast<void*>(w), 0, 1)};
     HIP_TRY(mpdata_layout_convert_cols(j2, 2, true, p->stream));
+    p->have_u = p->have_w = true;
   } else {
-    if (!rc && u) rc = one(1, u, p->sz.u, 0);
-    if (!rc && w) rc = one(2, w, p->sz.w, 0);
+    if (!rc && u) { rc = one(1, u, p->sz.u, 0); if (!rc) p->have_u = true; }
+    if (!rc && w) { rc = one(2, w, p->sz.w, 0); if (!rc) p->have_w = true; }
   }
   if (!rc && rho) rc = one(3, rho, p->sz.k, 0);
   if (!rc && rhow) rc = one(4, rhow, p->sz.kz, 0);
@@ -599,6 +627,17 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
     p->ntiles = (int)((p->wm_ncrms + p->slp - 1) / p->slp);
     p->chunk = (long long)p->slp * nzm;
     p->main_e = p->chunk * web / 128 * (128 / web);
+    // The counted waits of the wave-major kernels (s_waitcnt vmcnt(N), mpdata_kernel_wm_body.h) count
+    // INSTRUCTIONS: every column-pair fetch of an array must issue exactly two -- the lanes of the
+    // line-aligned main part in one, the other lanes in the second --, so both lane sets must be
+    // non-empty: 128 <= main part <= 384 bytes.  True for every (LPS, nz) the kernels are built for
+    // (chunk = (64/LPS) * nzm * 8 bytes with LPS/2 <= nzm < LPS, nz >= 3: 128 .. 504 bytes); checked
+    // here so that a future tiling cannot break the wait silently.
+    if (p->main_e * web < 128 || p->main_e * web > 384) {
+      free(p);
+      return set_err(MPDATA_EUNSUPPORTED, "internal: column chunk of %lld bytes breaks the two-instructions-per-fetch "
+                                          "invariant of the wave-major kernels", (long long)(p->chunk * web));
+    }
     {  // tiles start on 128-byte lines, an ODD number of lines apart (a power-of-two-ish stride
        // would put the same column of every tile on the same HBM channels: measured -5 %)
       long long lines = ((long long)(nx + 6) * p->chunk * web + 127) / 128;
@@ -640,6 +679,17 @@ int mpdata_plan_create_f32(int64_t ncrms, int nx, int nz, int ntracers, mpdata_p
   return plan_create(ncrms, nx, nz, ntracers, plan, 4);
 }
 
+// flux of every tracer := 0 on the plan's stream (an upload without a flux array: level nz and tracers
+// that are never run then download as zeros); also used by the multi-GPU upload on its per-GPU plans
+extern "C++" int mpdata_plan_zero_flux_internal(mpdata_plan* p) {
+  DevGuard g(p->device);
+  void* fl = p->layout == MPDATA_LAYOUT_REFERENCE ? p->flux : p->flux_ref;
+  HIP_TRY(hipMemsetAsync(fl, 0, p->sz.kz * p->ntracers * p->eb, p->stream));
+  if (p->layout == MPDATA_LAYOUT_WAVEMAJOR)
+    HIP_TRY(hipMemsetAsync(p->pflux, 0, (size_t)p->ntiles * p->chunk * p->ntracers * 8, p->stream));
+  return 0;
+}
+
 static int plan_upload(mpdata_plan* p, const void* f, const void* u, const void* w, const void* rho,
                        const void* rhow, const void* adz, const void* flux, int eb) {
   int rc = plan_check(p, eb);
@@ -653,11 +703,9 @@ static int plan_upload(mpdata_plan* p, const void* f, const void* u, const void*
   DevGuard g(p->device);
   // flux is intent(out) in the reference but its level nz is never written
   // (reference :541, :624 touch 1..nzm only): carry the caller's values over
-  void* fl = p->layout == MPDATA_LAYOUT_REFERENCE ? p->flux : p->flux_ref;
   if (!flux) {
-    HIP_TRY(hipMemsetAsync(fl, 0, p->sz.kz * p->ntracers * eb, p->stream));
-    if (p->layout == MPDATA_LAYOUT_WAVEMAJOR)
-      HIP_TRY(hipMemsetAsync(p->pflux, 0, (size_t)p->ntiles * p->chunk * p->ntracers * 8, p->stream));
+    rc = mpdata_plan_zero_flux_internal(p);
+    if (rc) return rc;
   }
   rc = plan_import(p, f, u, w, rho, rhow, adz, flux, 0, p->ntracers, false);
   if (rc) return rc;
@@ -766,6 +814,9 @@ int mpdata_plan_run_tracers(mpdata_plan* p, int first, int count) {
     return rc;
   }
   if (!p->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run before mpdata_plan_upload");
+  if (!p->have_u || !p->have_w)
+    return set_err(MPDATA_ESTATE, "mpdata_plan_run: the plan holds no velocities (none imported yet, or mpdata_plan_run_uw "
+                                  "ran since -- it leaves none behind): import u and w first");
   DevGuard g(p->device);
   if (p->timing) HIP_TRY(hipEventRecord(p->ev0, p->stream));
   rc = plan_launch(p, first, count);
@@ -788,8 +839,15 @@ int mpdata_plan_run_uw(mpdata_plan* p, int first, int count, const void* u, cons
   int rc = tracer_range(p, first, count);
   if (rc) return rc;
   if (p->multi) {   // u, w: full-width arrays on the root GPU -- scatter them (RCCL over xGMI), then every GPU runs
+    for (int g = 0; g < mpdata_multi_ngpus(p->multi); ++g)
+      if (!mpdata_multi_sub(p->multi, g)->uploaded) return set_err(MPDATA_ESTATE, "mpdata_plan_run_uw before upload / import (shard %d)", g);
     rc = mpdata_multi_scatter_device(p->multi, nullptr, u, w, nullptr, nullptr, nullptr, nullptr, 0, 0);
     if (!rc) rc = mpdata_multi_run(p->multi, first, count);
+    // the same post-condition as on one GPU: no velocities are left behind
+    for (int g = 0; g < mpdata_multi_ngpus(p->multi); ++g) {
+      mpdata_plan* q = mpdata_multi_sub(p->multi, g);
+      q->have_u = q->have_w = false;
+    }
     if (!rc) p->ran = true;
     return rc;
   }
@@ -803,12 +861,17 @@ int mpdata_plan_run_uw(mpdata_plan* p, int first, int count, const void* u, cons
   const bool direct = p->layout == MPDATA_LAYOUT_WAVEMAJOR && p->eb == 8 && count == 1 && (p->ncrms & 1) == 0 && p->lps <= 32 &&
                       (((uintptr_t)u | (uintptr_t)w) & 15) == 0 &&
                       (double)p->ncrms * (p->nx + 5) * p->nz * 8.0 < 4294967000.0 && !force_import;
+  // POST-CONDITION, the same on every path (which one runs depends on alignment, parity of ncrms, nz,
+  // the tracer count ...): the plan holds NO velocities afterwards.  The direct kernel never writes the
+  // plan's u, w (they would be stale), the conversion path overwrites them (they would be the new
+  // ones): neither is promised, mpdata_plan_run returns MPDATA_ESTATE until u, w are imported again.
+  p->have_u = p->have_w = false;
   if (direct) {
     rc = plan_launch(p, first, count, u, w);
   } else {
     rc = plan_import(p, nullptr, u, w, nullptr, nullptr, nullptr, nullptr, 0, 1, true);
-    if (rc) return rc;
-    rc = plan_launch(p, first, count);
+    if (!rc) rc = plan_launch(p, first, count);
+    p->have_u = p->have_w = false;
   }
   if (rc) return rc;
   if (p->timing) HIP_TRY(hipEventRecord(p->ev1, p->stream));
@@ -1185,6 +1248,18 @@ int mpdata_device_alloc(void** p, int64_t bytes) {
   HIP_TRY(hipMalloc(p, (size_t)bytes));
   return 0;
 }
+// ... on the device a plan's full-width arrays must live on: the plan's own device, the ROOT GPU
+// (shard 0's device) of a multi-GPU plan
+int mpdata_plan_device_alloc(mpdata_plan* plan, void** p, int64_t bytes) {
+  if (!plan) return set_err(MPDATA_EINVAL, "null plan");
+  int dev = plan->device;
+  if (plan->multi) {
+    const int rc = mpdata_multi_info(plan->multi, 0, &dev, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  DevGuard g(dev);
+  return mpdata_device_alloc(p, bytes);
+}
 int mpdata_device_free(void* p) {
   if (p) HIP_TRY(hipFree(p));
   return 0;
@@ -1209,6 +1284,7 @@ __global__ void sum_kernel(const double* a, long long n, long long block, long l
 }  // namespace
 int mpdata_device_sum(const double* a, int64_t n, int64_t block, int64_t stride, double* sum) {
   if (!a || !sum || n < 1 || block < 1 || stride < block) return set_err(MPDATA_EINVAL, "bad argument to mpdata_device_sum");
+  DevGuard g(device_of(a));
   double* part = nullptr;
   HIP_TRY(hipMalloc(&part, SUM_BLOCKS * sizeof(double)));
   hipLaunchKernelGGL(sum_kernel, dim3(SUM_BLOCKS), dim3(SUM_THREADS), 0, nullptr, a, (long long)n, (long long)block,

@@ -886,6 +886,10 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     const int P = ((q + 1) >> 1) + 3;
     if (2 * P + 1 <= nx + 4) dma_pair_full(P); else dma_pair(P);
   };
+// The counts are INSTRUCTION counts: a pair fetch of an array issues one DMA instruction for the lanes of
+// the main part and one for the other lanes (hipcc keeps an s_cbranch_execz around each, so an empty lane
+// set would issue none) -- both sets are non-empty because 128 <= mainB <= 384, which plan_create asserts
+// (mpdata_capi.hip).
 // The counted waits only rely on LOADS returning in issue order: "at most as many operations
 // outstanding as DMA instructions were issued after the pair's own".  (Counting the column stores
 // issued in between as well -- vmcnt(10) / vmcnt(5) -- is a race: a store may be acknowledged

@@ -476,17 +476,51 @@ static int gather_all(mpdata_multi* m, void* f, void* flux, int first, int count
 
 int mpdata_multi_upload(mpdata_multi* m, const void* f, const void* u, const void* w, const void* rho,
                         const void* rhow, const void* adz, const void* flux) {
-  // (flux == NULL: the per-GPU plans hold zeros since their creation -- flux(:,nz) is never written
-  //  by the routine, reference :541, :624)
+  // flux == NULL: zeros for every tracer, on every upload, exactly as a single-GPU plan does it (a
+  // memset per GPU instead of a transfer; flux(:,nz) is never written by the routine, reference
+  // :541, :624, so whatever an earlier upload left there would otherwise come back)
+  if (!flux) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = 0;
+    for (int g = 0; g < m->ngpus && !rc; ++g) rc = mpdata_plan_zero_flux_internal(m->sub[g]);
+    (void)hipSetDevice(prev);
+    if (rc) return rc;
+  }
   return scatter_all(m, f, u, w, rho, rhow, adz, flux, 0, m->ntracers, true);
 }
 // reference-layout arrays of the GLOBAL problem that live on the root GPU (device 0 of the plan):
 // NULL pointers are skipped; f / flux cover tracers [first, first + count)
+// The full-width arrays of a device scatter / gather must live on the ROOT GPU (shard 0's device): the
+// pack kernel runs there and dereferences them.  A pointer that HIP knows to belong to another
+// device (or to the host) is refused instead of being handed to that kernel.
+static int on_root(const mpdata_multi* m, const void* p, const char* name) {
+  if (!p) return 0;
+  hipPointerAttribute_t a;
+  const hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return mpdata_internal_set_err(MPDATA_EINVAL, "%s: not a device pointer HIP knows (%s); the arrays of a device scatter / gather "
+                                   "live on the plan's root GPU, device %d", name, hipGetErrorString(e), m->dev[0]);
+  }
+  if (a.type == hipMemoryTypeManaged) return 0;
+  if (a.type != hipMemoryTypeDevice || a.device != m->dev[0])
+    return mpdata_internal_set_err(MPDATA_EINVAL, "%s lives on %s %d, but the full-width arrays of a multi-GPU plan must be on its "
+                                   "root GPU, device %d (mpdata_plan_shard(plan, 0, &device, ...))", name,
+                                   a.type == hipMemoryTypeDevice ? "device" : "the host / memory type", a.type == hipMemoryTypeDevice ? a.device : (int)a.type,
+                                   m->dev[0]);
+  return 0;
+}
 int mpdata_multi_scatter_device(mpdata_multi* m, const void* f, const void* u, const void* w, const void* rho,
                                 const void* rhow, const void* adz, const void* flux, int first, int count) {
+  const void* ps[7] = {f, u, w, rho, rhow, adz, flux};
+  static const char* const nm[7] = {"f", "u", "w", "rho", "rhow", "adz", "flux"};
+  for (int i = 0; i < 7; ++i) M_TRY(on_root(m, ps[i], nm[i]));
   return scatter_all(m, f, u, w, rho, rhow, adz, flux, first, count, false);
 }
 int mpdata_multi_gather_device(mpdata_multi* m, void* f, void* flux, int first, int count) {
+  M_TRY(on_root(m, f, "f"));
+  M_TRY(on_root(m, flux, "flux"));
   return gather_all(m, f, flux, first, count, false);
 }
 

@@ -103,6 +103,12 @@ module mpdata_hip_mod
       type(c_ptr) :: ptr
       integer(c_int64_t), value :: bytes
     end function
+    integer(c_int) function mpdata_plan_device_alloc_c(plan, ptr, bytes) bind(C, name="mpdata_plan_device_alloc")
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: plan
+      type(c_ptr) :: ptr
+      integer(c_int64_t), value :: bytes
+    end function
     integer(c_int) function mpdata_device_free_c(ptr) bind(C, name="mpdata_device_free")
       import :: c_int, c_ptr
       type(c_ptr), value :: ptr
@@ -240,12 +246,14 @@ contains
     ! generator ids (the reference's fill order, :654-660): 0 adz, 1 f, 2 u, 3 w, 4 rho, 5 rhow, 6 flux
     rows = [ int(nzm, 8), int(nx+6, 8)*nzm*ntracers, int(nx+5, 8)*nzm, int(nx+4, 8)*nz, int(nzm, 8), int(nz, 8), &
              int(nz, 8)*ntracers ]
+    ! the plan first: the global arrays must live on ITS root GPU (shard 0's device; with
+    ! MPDATA_MULTI_DEVICES=3,4 that is device 3, not the current one)
+    call create_plan(plan)
     do i = 0, 6
-      call mpdata_check(mpdata_device_alloc_c(d(i), rows(i)*nslices*8_8), 'mpdata_device_alloc')
+      call mpdata_check(mpdata_plan_device_alloc_c(plan, d(i), rows(i)*nslices*8_8), 'mpdata_plan_device_alloc')
       call mpdata_check(mpdata_fill_synthetic_device_c(d(i), int(i, c_int), rows(i), nslices, 0_8, nslices, seed, &
                                                        int(dist, c_int), c_null_ptr), 'mpdata_fill_synthetic_device')
     end do
-    call create_plan(plan)
     ranks = mpdata_plan_ranks_seen_c(plan)
     ! scatter (ngpus > 1) / layout entry; twice: the first run is the warm-up the reference's first
     ! OpenACC call pays as well, the second import restores the inputs for the timed run

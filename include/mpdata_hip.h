@@ -112,10 +112,15 @@ int mpdata_plan_run_tracers(mpdata_plan* plan, int first_tracer, int ntracers); 
  * takes whatever u, w the device arrays hold, :107-110), f, rho, rhow, adz stay in the plan.
  * Entering the plan layout is part of the call and of its event time.  One fp64 tracer of a
  * wave-major plan: a kernel that reads u, w straight from the reference layout (128-byte row
- * segments through an LDS ring shared by the 8 waves of a workgroup) while f streams in the
- * plan layout -- no conversion pass; tracer batches: one fused u+w conversion, then the batch
- * kernel (the plan's u, w are then the new ones).  On a multi-GPU plan u, w are full-width
- * arrays on the root GPU: they are scattered (section 3b), then every GPU runs. */
+ * segments through an LDS ring shared by the waves of a workgroup) while f streams in the
+ * plan layout -- no conversion pass; other calls (tracer batches, fp32, odd ncrms, unaligned
+ * bases ...) convert on the way.  On a multi-GPU plan u, w are full-width arrays on the root GPU:
+ * they are scattered (section 3b), then every GPU runs.
+ * POST-CONDITION (the same on every path): the plan holds NO velocities afterwards -- whether its
+ * own u, w were left alone or overwritten depends on the path and is not promised.
+ * mpdata_plan_run / _run_tracers return MPDATA_ESTATE until u AND w have been handed over again
+ * (mpdata_plan_upload, or mpdata_plan_import_device with u and w); further mpdata_plan_run_uw
+ * calls need nothing. */
 int mpdata_plan_run_uw(mpdata_plan* plan, int first_tracer, int ntracers, const void* u, const void* w);
 int mpdata_plan_sync(mpdata_plan* plan);           /* the `!$acc wait` (:237) */
 int mpdata_plan_download(mpdata_plan* plan, double* f, double* flux);  /* host arrays */
@@ -188,8 +193,14 @@ int mpdata_fill_synthetic_device(double* a, int sid, int64_t rows, int64_t ncrms
  * of the elements j < n with (j mod stride) < block (block = stride = n: all of them), in a fixed
  * order (a checksum, reproducible run to run). */
 int mpdata_device_alloc(void** ptr, int64_t bytes);   /* on the current device */
+/* ... on the device a plan takes full-width device arrays from: its own device; the ROOT GPU (shard
+ * 0's device) of a multi-GPU plan.  mpdata_plan_import_device / _export_device / _run_uw on a
+ * multi-GPU plan return MPDATA_EINVAL for an array that lives anywhere else. */
+int mpdata_plan_device_alloc(mpdata_plan* plan, void** ptr, int64_t bytes);
 int mpdata_device_free(void* ptr);
 int mpdata_device_sum(const double* a, int64_t n, int64_t block, int64_t stride, double* sum);
+/* (mpdata_fill_synthetic_device with a NULL stream and mpdata_device_sum run on the device the array
+ * lives on, whatever the current device is.) */
 
 /* ---- 5. Shard pack/unpack for the multi-GPU scatter/gather (device
  * pointers).  A shard [sl0, sl0+nloc) of an array with leading dimension

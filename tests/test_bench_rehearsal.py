@@ -12,22 +12,29 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.gpu
-def test_two_rank_bench_prints_one_whole_job_line():
+def _two_ranks(extra_env=None, extra_args=()):
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a port the OS hands out
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MPDATA_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MPDATA_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--ncrms-per-gpu", "4096",
-           "--batched-tracers", "3", "--batched-steps", "2", "--no-fp32", "--no-bwk", "--no-cpu-baseline"]
+           "--batched-tracers", "3", "--batched-steps", "2", "--no-fp32", "--no-bwk", "--no-cpu-baseline", *extra_args]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout                     # rank 0 only
-    d = json.loads(lines[0])
+    return json.loads(lines[0]), res
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_prints_one_whole_job_line():
+    d, res = _two_ranks()
+    # the headline is on stderr the moment it exists, before any side block runs
+    early = [ln for ln in res.stderr.splitlines() if "BENCH_HEADLINE {" in ln]
+    assert len(early) == 1 and json.loads(early[0].split("BENCH_HEADLINE ", 1)[1])["value"] == d["value"]
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["config"]["ncrms_global"] == 2 * 4096
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
@@ -37,3 +44,24 @@ def test_two_rank_bench_prints_one_whole_job_line():
     assert d["reference_layout_device_call"]["value"] > 0
     assert d["twice_the_instances"]["value"] > 0 and "ncrms=8192/GPU" in d["twice_the_instances"]["workload"]
     assert "scatter_gather" in d      # (gloo cannot move device tensors: an error entry in the rehearsal)
+
+
+@pytest.mark.gpu
+def test_a_side_block_that_raises_on_one_rank_cannot_lose_the_line():
+    """One rank raises in the MIDDLE of a side block's timed loop (after its warm-up), another block raises
+    at its start on the other rank: no rank may be left waiting in a barrier (the run ends, rc 0), the
+    headline is intact, the two blocks carry an error entry and the blocks after them still ran."""
+    d, res = _two_ranks({"MPDATA_BENCH_FAIL": "tracer_batched:1:mid,reference_layout_device_call:0"})
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0 and d["steps"] == 3
+    assert "error" in d["tracer_batched"] and "value" not in d["tracer_batched"]
+    assert "InjectedFailure" in d["reference_layout_device_call"]["error"]
+    assert d["twice_the_instances"]["value"] > 0 and d["step_with_fresh_uw"]["value"] > 0
+    assert "scatter_gather" in d
+
+
+@pytest.mark.gpu
+def test_headline_only():
+    d, _ = _two_ranks(extra_args=("--headline-only",))
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    for k in ("tracer_batched", "twice_the_instances", "reference_layout_device_call", "fp32", "scatter_gather"):
+        assert k not in d

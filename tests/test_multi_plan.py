@@ -214,3 +214,57 @@ def test_multi_plan_run_uw_scatters_fresh_velocities(mpdata, oracle):
     f_ref, flux_ref = oracle.advect(inp, nthreads=4)
     assert np.array_equal(to_host(fo), f_ref)
     assert np.allclose(to_host(flo)[:, :-1], flux_ref[:, :-1], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_multi_plan_upload_without_flux_zeroes_it_every_time(mpdata, oracle, monkeypatch):
+    """An upload with flux = NULL hands every tracer a zero flux array on EVERY upload, as a single-GPU plan
+    does -- also when an earlier upload of the same plan carried values (flux(:,nz) is never written by the
+    routine, reference :541, :624, so stale values would come back with the download)."""
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    monkeypatch.setenv("MPDATA_MULTI_XFER", "direct")
+    shape, T = (70, 9, 12), 2
+    inp = _make(oracle, *shape, T)
+    assert np.abs(inp["flux"][:, -1]).max() > 0
+    outs = []
+    for devices in (None, [0, 0]):
+        p = M.Plan(*shape, T) if devices is None else M.Plan(*shape, T, devices=devices)
+        p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+        p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], None)
+        p.run(0, 1); p.sync()       # tracer 1 is never run: its flux stays what the upload made it
+        f = np.empty_like(inp["f"], order="F"); flux = np.full_like(inp["flux"], 7.0, order="F")
+        p.download(f, flux)
+        p.close()
+        assert np.all(flux[:, -1, :] == 0.0) and np.all(flux[..., 1] == 0.0)
+        outs.append((f, flux))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.gpu
+def test_multi_plan_refuses_full_width_arrays_that_are_not_on_its_root_gpu(mpdata, oracle):
+    """import_device / export_device / run_uw of a multi-GPU plan dereference the caller's arrays in a pack
+    kernel on the ROOT GPU: a pointer HIP attributes to the host (here: pinned host memory) is refused with
+    MPDATA_EINVAL instead of being handed to that kernel; mpdata_plan_device_alloc allocates on the root."""
+    import ctypes
+    import torch
+    from util import to_dev
+    M = mpdata
+    shape = (64, 9, 12)
+    inp = _make(oracle, *shape, 1)
+    d = {k: to_dev(v) for k, v in inp.items()}
+    p = M.Plan(*shape, 1, devices=[0, 0])
+    pinned = torch.empty(d["u"].shape, dtype=torch.float64).pin_memory()
+    L = M.lib()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = L.mpdata_plan_import_device(p._p, vp(d["f"]), vp(pinned), vp(d["w"]), vp(d["rho"]), vp(d["rhow"]), vp(d["adz"]),
+                                     vp(d["flux"]), 0, 1)
+    assert rc == M.EINVAL and b"root GPU" in L.mpdata_last_error()
+    p.import_device(d["f"], d["u"], d["w"], d["rho"], d["rhow"], d["adz"], d["flux"])
+    assert L.mpdata_plan_run_uw(p._p, 0, 1, vp(pinned), vp(d["w"])) == M.EINVAL
+    pf = torch.empty(d["f"].shape, dtype=torch.float64).pin_memory()
+    assert L.mpdata_plan_export_device(p._p, vp(pf), None, 0, 1) == M.EINVAL
+    ptr = ctypes.c_void_p()
+    assert L.mpdata_plan_device_alloc(p._p, ctypes.byref(ptr), 4096) == 0 and ptr.value
+    assert L.mpdata_device_free(ptr) == 0
+    p.close()

@@ -103,15 +103,16 @@ def test_run_uw_reference_raw_inputs(M, oracle, variant):
 
 
 def test_run_uw_tracer_batch_converts(M, oracle):
-    """ntracers > 1: one u + w conversion, then the batch kernel; the plan's velocities are the new ones."""
+    """ntracers > 1: the velocities enter the plan layout on the way (no separate reading kernel exists for
+    tracer batches)."""
     run_uw_case(M, oracle, (64, 32, 28), "exact", dist=3, seed=9, ntr=3)
     run_uw_case(M, oracle, (50, 7, 12), "exact", dist=1, seed=10, ntr=2)
 
 
 def test_run_uw_one_tracer_of_a_multi_tracer_plan(M, oracle):
     """run_uw(first_tracer=1, ntracers=1) on a 3-tracer plan: the kernel that reads u, w from the reference
-    layout works on that tracer alone; the other two keep their fields, and the plan's OWN u, w are untouched
-    (a later plain run of tracer 2 still uses the uploaded ones)."""
+    layout works on that tracer alone; the other two keep their fields.  Tracer 2 is run on the plan's own
+    (uploaded) velocities BEFORE the run_uw step."""
     import torch
     M.set_variant(M.VARIANT_EXACT)
     ncrms, nx, nz = 96, 32, 28
@@ -123,8 +124,8 @@ def test_run_uw_one_tracer_of_a_multi_tracer_plan(M, oracle):
     up["flux"] = np.asfortranarray(np.stack([inp["flux"]] * 3, axis=-1))
     p = M.Plan(ncrms, nx, nz, 3)
     p.upload(up["f"], up["u"], up["w"], up["rho"], up["rhow"], up["adz"], up["flux"])
-    p.run_uw(to_dev(inp["u"]), to_dev(inp["w"]), first_tracer=1, ntracers=1)
     p.run(2, 1)            # tracer 2 with the plan's own (other) velocities
+    p.run_uw(to_dev(inp["u"]), to_dev(inp["w"]), first_tracer=1, ntracers=1)
     p.sync()
     f = np.empty_like(up["f"], order="F"); flux = np.empty_like(up["flux"], order="F")
     p.download(f, flux)
@@ -134,6 +135,57 @@ def test_run_uw_one_tracer_of_a_multi_tracer_plan(M, oracle):
     assert np.array_equal(f[..., 1], f1_ref)
     f2_ref, _ = oracle.advect(dict(inp, u=other["u"], w=other["w"], f=fs[2].copy()), nthreads=4)   # the plan's u, w
     assert np.array_equal(f[..., 2], f2_ref)
+
+
+@pytest.mark.parametrize("case", ["direct", "odd-ncrms", "tracer-batch", "unaligned", "reference-layout-plan", "fp32"])
+def test_run_uw_leaves_no_velocities_on_any_path(M, oracle, case):
+    """The post-condition of mpdata_plan_run_uw does not depend on the path the call took (the kernel that
+    reads the caller's arrays leaves the plan's u, w alone, the converting paths overwrite them): afterwards
+    the plan holds NO velocities -- mpdata_plan_run returns MPDATA_ESTATE until u and w are imported again,
+    and then advects with the imported ones."""
+    import torch
+    M.set_variant(M.VARIANT_EXACT)
+    ncrms, nx, nz, ntr = {"odd-ncrms": (37, 9, 12, 1), "tracer-batch": (64, 9, 12, 2)}.get(case, (64, 9, 12, 1))
+    f32 = case == "fp32"
+    dt = np.float32 if f32 else np.float64
+    inp = oracle.make_inputs(ncrms, nx, nz, seed=61, dist=1, dtype=dt)
+    other = oracle.make_inputs(ncrms, nx, nz, seed=62, dist=1, dtype=dt)
+    prev = M.set_plan_layout(M.LAYOUT_REFERENCE) if case == "reference-layout-plan" else None
+    try:
+        p = M.Plan(ncrms, nx, nz, ntr, dtype=dt)
+    finally:
+        if prev is not None:
+            M.set_plan_layout(prev)
+    d = {k: to_dev(v) for k, v in inp.items()}
+    do = {k: to_dev(v) for k, v in other.items()}
+    for t in range(ntr):
+        p.import_device(d["f"], do["u"], do["w"], d["rho"], d["rhow"], d["adz"], d["flux"], first_tracer=t)
+    p.run(0, 1)                                   # the plan has velocities: fine
+    if case == "unaligned":
+        ub = torch.empty(inp["u"].size + 1, dtype=torch.float64, device="cuda:0")
+        wb = torch.empty(inp["w"].size + 1, dtype=torch.float64, device="cuda:0")
+        du = ub[1:].view(d["u"].shape); du.copy_(d["u"])
+        dw = wb[1:].view(d["w"].shape); dw.copy_(d["w"])
+    else:
+        du, dw = d["u"], d["w"]
+    p.run_uw(du, dw)
+    with pytest.raises(M.MpdataError) as ei:
+        p.run()
+    assert ei.value.code == M.ESTATE and "velocities" in str(ei.value)
+    with pytest.raises(M.MpdataError):
+        p.run(0, 1)
+    p.import_device(None, do["u"], None)          # u alone is not enough
+    with pytest.raises(M.MpdataError):
+        p.run()
+    p.run_uw(du, dw)                              # (another run_uw needs nothing)
+    p.import_device(d["f"], do["u"], do["w"])     # both again (and a fresh f for tracer 0)
+    p.run(0, 1)
+    fo = torch.empty_like(d["f"])
+    p.export_device(fo)
+    p.sync()
+    p.close()
+    f_ref, _ = oracle.advect(dict(inp, u=other["u"], w=other["w"]), nthreads=4)
+    assert np.array_equal(to_host(fo), f_ref)
 
 
 def test_run_uw_unaligned_bases_convert(M, oracle):
