@@ -46,6 +46,7 @@ struct MpdataWmArgsT {
   const R* u_ref;          // u(ncrms, nx+5, nzm)
   const R* w_ref;          // w(ncrms, nx+4, nz)
   long long ncrms;         // leading dimension of u_ref, w_ref
+  unsigned long long* dbg; // diagnostic builds only (-DMPDWM_STAMPS): 8 words per wave (tools/wave_timeline.py); else null
 };
 typedef MpdataWmArgsT<double> MpdataWmArgs;
 // test switches of the wave-major launch (mpdata_set_wm_flags; MPDATA_WM_NOSTREAM / _TPW1 / _NOSPLIT)

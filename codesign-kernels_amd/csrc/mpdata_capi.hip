@@ -375,7 +375,10 @@ int wm_flags() {
                  (getenv("MPDATA_WM_NOSPLIT") ? MPDATA_WMF_NOSPLIT : 0);
   return g_wm_flags;
 }
-int wm_wpb() { return 4; }  // waves (tiles) per workgroup of the wave-major kernels
+#ifndef MPDWM_WPB
+#define MPDWM_WPB 4
+#endif
+int wm_wpb() { return MPDWM_WPB; }  // waves (tiles) per workgroup of the wave-major kernels
 struct DevGuard {
   int prev = -1, dev;
   explicit DevGuard(int d) : dev(d) {
@@ -774,6 +777,7 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
     a.flux_tstride = (long long)p->ntiles * p->chunk;
     a.reverse = serpentine() ? (int)(p->runs++ & 1u) : 0;
     a.u_ref = (const double*)u_ref; a.w_ref = (const double*)w_ref; a.ncrms = p->ncrms;
+    a.dbg = g_dbg;   // (null unless a diagnostic build was handed a stamp buffer)
     const bool fast = p->variant == MPDATA_VARIANT_FAST;
     if (u_ref) {
       a.reverse = 0;

@@ -271,6 +271,23 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     if (a.reverse) tile = (unsigned)a.ntiles - 1u - tile;
   }
 
+#ifdef MPDWM_STAMPS
+  // diagnostic build (tools/wave_timeline.py): every wave records its start / end on the 100-MHz
+  // real-time counter and the shader clock, the shader cycles it spent in the counted DMA waits and
+  // where it ran (HW_ID, XCC_ID): 8 words per wave at dbg[8 * (tracer-launch wave index)]
+  unsigned long long st_r0, st_c0, st_wait = 0;
+  asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_r0), "=s"(st_c0)::"memory");
+#define MPDWM_WAIT(STR)                                                                             \
+  {                                                                                                 \
+    unsigned long long ta_, tb_;                                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ta_)::"memory");                     \
+    asm volatile(STR ::: "memory");                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");                     \
+    st_wait += tb_ - ta_;                                                                           \
+  }
+#else
+#define MPDWM_WAIT(STR) asm volatile(STR ::: "memory");
+#endif
   const int chunk = SLP * nzm;                    // elements of one column of the tile
   const unsigned chunkB = (unsigned)(chunk * RB);
   const long long toff = (long long)tile * a.tile_elems;
@@ -902,7 +919,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
        pair and f of the one after: 3 x 2 instructions), every LDS read of the previous pair \
        has returned; after the barrier the same holds for the whole workgroup: the pair's u, \
        w are complete and the slot of the previous pair is free for the pair after next */   \
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); \
+    MPDWM_WAIT("s_waitcnt vmcnt(6) lgkmcnt(0)")         \
     __builtin_amdgcn_s_barrier();                       \
     asm volatile("" ::: "memory");                      \
     MPDWM_FLUSH_DEFERRED                                \
@@ -915,8 +932,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     if (MPDWX_UW_POS == 2) dma_uw((((q) + 2) >> 1) + 2); \
     DMA((q) + 1);                                       \
   } else if constexpr (TPW == 1) {                      \
-    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+    if constexpr (STREAM) MPDWM_WAIT("s_waitcnt vmcnt(12)") \
+    else MPDWM_WAIT("s_waitcnt vmcnt(6)")               \
     MPDWM_FLUSH_DEFERRED                                \
     step(PHA{}, SL{}, I0{}, TAG{}, (q), in_e);          \
     asm volatile("" ::: "memory");                      \
@@ -926,7 +943,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   } else {                                              \
     const LdsIn in_o = lds_in(SL{}, I1{});              \
     step(PHA{}, SL{}, I0{}, TAG{}, (q), in_e);          \
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    \
+    MPDWM_WAIT("s_waitcnt vmcnt(4)")                    \
     MPDWM_FLUSH_DEFERRED                                \
     in_e = lds_in(SLN{}, I0{});                         \
     step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1, in_o);      \
@@ -999,7 +1016,21 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     if constexpr (TPW == 2)
       if (lvl_ok && has1) flux1[pos] = second(fl);
   }
+#ifdef MPDWM_STAMPS
+  if (a.dbg) {
+    unsigned long long r1, c1;
+    unsigned hw, xcc;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_memtime %1\n\ts_getreg_b32 %2, hwreg(HW_REG_HW_ID)\n\t"
+                 "s_getreg_b32 %3, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(r1), "=s"(c1), "=s"(hw), "=s"(xcc)::"memory");
+    unsigned long long* o = a.dbg + 8ull * ((unsigned long long)blockIdx.x * WPB + (unsigned)wave);
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+      o[0] = st_r0; o[1] = r1; o[2] = st_c0; o[3] = c1; o[4] = st_wait; o[5] = hw; o[6] = xcc; o[7] = tile;
+    }
+  }
+#endif
 }
+#undef MPDWM_WAIT
 
 }  // namespace wm
 }  // namespace MPDATA_NS

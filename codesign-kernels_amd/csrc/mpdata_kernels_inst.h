@@ -73,6 +73,11 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
 // wave-major kernels (mpdata_kernel_wm_body.h, the plan API): LPS = lanes per instance (>= nz),
 // WPB = waves per workgroup.  Returns false if (lps, wpb) is not instantiated.
 #define MPDATA_WM_LPS(X) X(8) X(16) X(32) X(64)
+// waves (= tiles) per workgroup of the plan kernels; the waves of a workgroup never synchronise, the
+// workgroup is only the unit in which the dispatcher hands out wave slots and LDS
+#ifndef MPDWM_WPB
+#define MPDWM_WPB 4
+#endif
 template <typename R, int LPS, int WPB>
 static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
   // ntracers == 1: wave = tile in dispatch order, u and w streamed; else the per-XCD tracer walk with
@@ -120,10 +125,10 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
   }
 }
 bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags) {
-  if (wpb != 4) return false;
+  if (wpb != MPDWM_WPB) return false;
 #define X(LPS_)                             \
   if (lps == LPS_) {                        \
-    launch_wm_t<double, LPS_, 4>(a, stream, flags); \
+    launch_wm_t<double, LPS_, MPDWM_WPB>(a, stream, flags); \
     return true;                            \
   }
   MPDATA_WM_LPS(X)
@@ -148,7 +153,7 @@ bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream) {
 // fp32 plans: two adjacent instances per lane (8-byte elements = pairs of fp32 values, packed
 // arithmetic); `a` describes the arrays in PAIRS (ncrms / 2 of them)
 bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stream, int flags) {
-  if (wpb != 4) return false;
+  if (wpb != MPDWM_WPB) return false;
   MpdataWmArgsT<v2::f32x2> a;
   a.f = reinterpret_cast<v2::f32x2*>(a8.f);
   a.u = reinterpret_cast<const v2::f32x2*>(a8.u);
@@ -157,10 +162,10 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   a.flux = reinterpret_cast<v2::f32x2*>(a8.flux);
   a.ntiles = a8.ntiles; a.nx = a8.nx; a.nz = a8.nz; a.ntracers = a8.ntracers;
   a.tile_elems = a8.tile_elems; a.f_tstride = a8.f_tstride; a.flux_tstride = a8.flux_tstride; a.reverse = a8.reverse;
-  a.u_ref = nullptr; a.w_ref = nullptr; a.ncrms = 0;
+  a.u_ref = nullptr; a.w_ref = nullptr; a.ncrms = 0; a.dbg = a8.dbg;
 #define X(LPS_)                                \
   if (lps == LPS_) {                           \
-    launch_wm_t<v2::f32x2, LPS_, 4>(a, stream, flags); \
+    launch_wm_t<v2::f32x2, LPS_, MPDWM_WPB>(a, stream, flags); \
     return true;                               \
   }
   MPDATA_WM_LPS(X)
@@ -194,6 +199,12 @@ const char* build_flags() {
 #endif
 #ifdef MPD2_STAMPS
          " MPD2_STAMPS"
+#endif
+#ifdef MPDWM_STAMPS
+         " MPDWM_STAMPS"
+#endif
+#if MPDWM_WPB != 4
+         " MPDWM_WPB"
 #endif
 #ifdef MPD2_NO_XCD_TRACERS
          " MPD2_NO_XCD_TRACERS"

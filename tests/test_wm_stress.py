@@ -58,9 +58,15 @@ def _flux_close(flux, ref):
 
 @pytest.mark.parametrize("form,launches,ntr,ncrms", [("batch-form-one-tracer", 200, 1, NCRMS), ("streaming", 100, 1, NCRMS),
                                                     ("run_uw", 100, 1, NCRMS), ("two-tracers-per-wave", 40, 3, 16384)])
-def test_every_launch_reproduces_the_first_under_memory_pressure(M, oracle, form, launches, ntr, ncrms):
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_every_launch_reproduces_the_first_under_memory_pressure(M, oracle, form, launches, ntr, ncrms, variant):
+    """EXACT and FAST are different instruction schedules of every form (FAST: the T1X / XSUM arithmetic, the
+    headline kernel): both are repeated; FAST half as often."""
     import torch
-    M.set_variant(M.VARIANT_EXACT)
+    fast = variant == "fast"
+    if fast:
+        launches = max(20, launches // 2)
+    M.set_variant(M.VARIANT_FAST if fast else M.VARIANT_EXACT)
     M.set_wm_flags(M.WMF_NOSTREAM if form == "batch-form-one-tracer" else 0)
     sh = M.shapes(ncrms, NX, NZ, 1)
     d = {k: torch.empty(s, dtype=torch.float64, device="cuda:0") for k, s in sh.items()}
@@ -109,5 +115,9 @@ def test_every_launch_reproduces_the_first_under_memory_pressure(M, oracle, form
             inp = dict(base)
             inp["f"] = oracle.fill_array("f", (n, NX + 6, NZ - 1), 100 + t, oracle.DIST_CONDITIONED, ncrms_global=ncrms, sl0=s0)
             f_ref, flux_ref = oracle.advect(inp)
-            assert np.array_equal(to_host(first_f[t][..., s0:s0 + n]), f_ref), (form, s0, t)
-            assert _flux_close(to_host(first_flux[t][..., s0:s0 + n]), flux_ref), (form, s0, t)
+            if fast:   # north_star tolerance on conditioned inputs
+                assert np.abs(to_host(first_f[t][..., s0:s0 + n]) - f_ref).max() < 1e-12, (form, s0, t)
+                assert np.abs(to_host(first_flux[t][..., s0:s0 + n]) - flux_ref)[:, :NZ - 1].max() < 1e-12, (form, s0, t)
+            else:
+                assert np.array_equal(to_host(first_f[t][..., s0:s0 + n]), f_ref), (form, s0, t)
+                assert _flux_close(to_host(first_flux[t][..., s0:s0 + n]), flux_ref), (form, s0, t)
