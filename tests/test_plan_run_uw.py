@@ -2,7 +2,8 @@
 reference-layout device u, w while f stays in the plan.  One fp64 tracer of a wave-major plan goes
 through the kernel that reads u, w straight from the reference layout (template option UWREF of
 mpdata_kernel_wm_body.h: 16-byte LDS-DMA of 128-byte row segments into a ring shared by the
-workgroup); other cases (tracer batches, odd ncrms, nz > 32, unaligned bases) convert u, w first.
+workgroup; nz 33 .. 64: one instance per wave, a 16-wave workgroup); tracer batches send their first tracer
+through the converting form of that kernel (nz <= 32); other cases (odd ncrms, unaligned bases, fp32) convert u, w first.
 
 The plans are uploaded with OTHER velocities than the ones the step is run on, so a kernel that
 read the plan's own u, w would fail.  Bars as in test_plan_wavemajor.py: EXACT -> f bit-identical
@@ -85,10 +86,12 @@ def run_uw_case(M, oracle, shape, variant, dist, seed, ntr=1, misalign=False):
             assert oracle.rel_l1(flt[:, :-1], flux_ref[:, :-1]) < TOL_RELL1, (shape, t)
 
 
-# even ncrms, nz <= 32: the UWREF kernel (ragged last workgroup: 258, 22, 2; every lane mapping 8 / 16 / 32;
-# nx from 1 upwards incl. every nx mod 6 class); the others take the conversion path
+# even ncrms: the UWREF kernel (ragged last workgroup: 258, 22, 2; every lane mapping 8 / 16 / 32 / 64 -- nz 33 .. 64
+# is one instance per wave, a 16-wave workgroup: the reference's shipped size 48 x 32 x 58 among them; nx from 1
+# upwards incl. every nx mod 6 class); odd ncrms takes the conversion path
 SHAPES = [(64, 32, 28), (258, 31, 28), (16, 1, 3), (22, 5, 7), (130, 31, 12), (2, 2, 4), (48, 33, 17), (34, 34, 32),
-          (18, 35, 9), (66, 36, 28), (20, 3, 32), (37, 32, 28), (10, 6, 64), (7, 2, 4)]
+          (18, 35, 9), (66, 36, 28), (20, 3, 32), (37, 32, 28), (10, 6, 64), (7, 2, 4), (48, 32, 58), (34, 7, 33),
+          (130, 5, 45), (18, 34, 64), (2, 1, 40), (50, 33, 58)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
@@ -102,11 +105,63 @@ def test_run_uw_reference_raw_inputs(M, oracle, variant):
     run_uw_case(M, oracle, (96, 32, 28), variant, dist=2, seed=5)
 
 
-def test_run_uw_tracer_batch_converts(M, oracle):
-    """ntracers > 1: the velocities enter the plan layout on the way (no separate reading kernel exists for
-    tracer batches)."""
-    run_uw_case(M, oracle, (64, 32, 28), "exact", dist=3, seed=9, ntr=3)
-    run_uw_case(M, oracle, (50, 7, 12), "exact", dist=1, seed=10, ntr=2)
+BATCHES = [((64, 32, 28), 3), ((258, 31, 28), 4), ((22, 5, 7), 2), ((130, 31, 12), 5), ((34, 34, 32), 3), ((2, 1, 3), 2),
+           ((66, 36, 28), 25), ((50, 7, 12), 2), ((48, 32, 58), 3), ((37, 9, 12), 3)]
+
+
+@pytest.mark.parametrize("shape,ntr", BATCHES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else f"T{v}")
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_run_uw_tracer_batches(M, oracle, shape, ntr, variant):
+    """ntracers > 1 on fresh velocities.  nz <= 32, even ncrms, aligned bases: the FIRST tracer of the batch goes
+    through the kernel that reads u, w from the reference layout in its converting form (it writes the values it
+    reads into the plan's arrays, plan layout), the others through the batch kernel behind it -- no conversion pass.
+    nz 33 .. 64 (48 x 32 x 58) and odd ncrms (37): one fused u + w conversion, then the batch kernel.  The plan was
+    uploaded with OTHER velocities.  Every tracer against the oracle."""
+    run_uw_case(M, oracle, shape, variant, dist=3 if variant == "exact" else 1, seed=9, ntr=ntr)
+
+
+def test_run_uw_tracer_batch_unaligned_bases_convert(M, oracle):
+    run_uw_case(M, oracle, (64, 32, 28), "exact", dist=3, seed=9, ntr=3, misalign=True)
+
+
+def test_run_uw_tracer_batch_full_size_sampled(M, oracle):
+    """ncrms = 65536 x 5 tracers on fresh u, w (the converting kernel + the batch kernel at full size): sampled
+    instance blocks of every tracer against the oracle, EXACT."""
+    import torch
+    ncrms, nx, nz, T = 65536, 32, 28, 5
+    M.set_variant(M.VARIANT_EXACT)
+    sh = M.shapes(ncrms, nx, nz, 1)
+    d = {k: torch.empty(s, dtype=torch.float64, device="cuda:0") for k, s in sh.items()}
+    for k in d:
+        M.fill_synthetic(d[k], k, 100, oracle.DIST_CONDITIONED)
+    p = M.Plan(ncrms, nx, nz, T)
+    p.import_device(None, torch.full_like(d["u"], 0.25), torch.full_like(d["w"], -0.125), d["rho"], d["rhow"], d["adz"], None)
+    ft = torch.empty_like(d["f"])
+    for t in range(T):
+        M.fill_synthetic(ft, "f", 100 + t, oracle.DIST_CONDITIONED)
+        p.import_device(ft, flux=d["flux"], first_tracer=t)
+    p.run_uw(d["u"], d["w"])
+    fo, flo = torch.empty_like(d["f"]), torch.empty_like(d["flux"])
+    for t in range(T):
+        p.export_device(fo, flo, first_tracer=t)
+        p.sync()
+        for s0, n in ((0, 40), (31000 + 1, 34), (65536 - 33, 33)):
+            inp = oracle.make_inputs(n, nx, nz, seed=100, dist=oracle.DIST_CONDITIONED, ncrms_global=ncrms, sl0=s0)
+            inp["f"] = oracle.fill_array("f", (n, nx + 6, nz - 1), 100 + t, oracle.DIST_CONDITIONED, ncrms_global=ncrms, sl0=s0)
+            f_ref, flux_ref = oracle.advect(inp)
+            assert np.array_equal(to_host(fo[..., s0:s0 + n]), f_ref), (t, s0)
+            assert flux_close(to_host(flo[..., s0:s0 + n]), flux_ref), (t, s0)
+    # the converted velocities the batch kernel used are the caller's: a later import + plain run agrees bitwise
+    p.import_device(None, d["u"], d["w"])
+    M.fill_synthetic(ft, "f", 100, oracle.DIST_CONDITIONED)
+    p.import_device(ft, first_tracer=3)
+    p.run(3, 1)
+    f3 = torch.empty_like(d["f"])
+    p.export_device(f3, first_tracer=3)
+    p.export_device(fo, first_tracer=0)
+    p.sync()
+    assert torch.equal(f3, fo)
+    p.close()
 
 
 def test_run_uw_one_tracer_of_a_multi_tracer_plan(M, oracle):
@@ -193,12 +248,12 @@ def test_run_uw_unaligned_bases_convert(M, oracle):
 
 
 def test_run_uw_random_shapes(M, oracle):
-    """30 seeded random shapes (even ncrms 2..400, nx 1..50, nz 3..32): EXACT f bit-identical."""
+    """30 seeded random shapes (even ncrms 2..400, nx 1..50, nz 3..64): EXACT f bit-identical."""
     rng = np.random.default_rng(20261104)
     for it in range(30):
         ncrms = 2 * int(rng.integers(1, 201))
         nx = int(rng.integers(1, 51))
-        nz = int(rng.choice([rng.integers(3, 9), rng.integers(9, 17), rng.integers(17, 33)]))
+        nz = int(rng.choice([rng.integers(3, 9), rng.integers(9, 17), rng.integers(17, 33), rng.integers(33, 65)]))
         run_uw_case(M, oracle, (ncrms, nx, nz), "exact", dist=3 if it % 3 else 1, seed=2000 + it)
 
 
