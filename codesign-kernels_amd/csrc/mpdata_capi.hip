@@ -507,8 +507,13 @@ int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, con
   // f, u, w (many columns, split chunks): the column-walking kernel; the small arrays: the per-column one
   auto conv = [&](int which, void* ref, int tr, int ntr) -> int {
     const MpdataLayoutJob j = wm_job(p, which, ref, tr, ntr);
-    if (which <= 2 && !legacy_convert()) HIP_TRY(mpdata_layout_convert_cols(&j, 1, true, p->stream));
-    else HIP_TRY(mpdata_layout_convert(j, 8, true, p->stream));
+    if (which <= 2 && !legacy_convert()) {
+      const hipError_t e = mpdata_layout_import_rows(&j, 1, p->stream);   // (row segments through LDS-DMA where possible)
+      if (e == hipErrorNotSupported) HIP_TRY(mpdata_layout_convert_cols(&j, 1, true, p->stream));
+      else HIP_TRY(e);
+    } else {
+      HIP_TRY(mpdata_layout_convert(j, 8, true, p->stream));
+    }
     return 0;
   };
   auto one = [&](int which, const void* src, size_t elems, int tr) -> int {
@@ -529,7 +534,9 @@ int plan_import(mpdata_plan* p, const void* f, const void* u, const void* w, con
   }
   if (!rc && u && w && dev && !legacy_convert()) {   // u and w of a device import: ONE launch
     const MpdataLayoutJob j2[2] = {wm_job(p, 1, const_cast<void*>(u), 0, 1), wm_job(p, 2, const_cast<void*>(w), 0, 1)};
-    HIP_TRY(mpdata_layout_convert_cols(j2, 2, true, p->stream));
+    const hipError_t e = mpdata_layout_import_rows(j2, 2, p->stream);
+    if (e == hipErrorNotSupported) HIP_TRY(mpdata_layout_convert_cols(j2, 2, true, p->stream));
+    else HIP_TRY(e);
     p->have_u = p->have_w = true;
   } else {
     if (!rc && u) { rc = one(1, u, p->sz.u, 0); if (!rc) p->have_u = true; }

@@ -36,4 +36,8 @@ hipError_t mpdata_layout_convert(const MpdataLayoutJob& j, int elem_bytes, bool 
 // all columns; nj = 1, or 2 arrays of equal nlev in one launch (u and w of an import)
 hipError_t mpdata_layout_convert_cols(const MpdataLayoutJob* jobs, int nj, bool to_private, hipStream_t stream);
 
+// import (reference -> plan) of f, u, w by 128-byte row segments through LDS-DMA; hipErrorNotSupported: conditions not
+// met (odd ncrms, unaligned base, array of 4 GiB or more), take mpdata_layout_convert_cols
+hipError_t mpdata_layout_import_rows(const MpdataLayoutJob* jobs, int nj, hipStream_t stream);
+
 #endif
