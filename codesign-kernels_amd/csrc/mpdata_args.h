@@ -20,7 +20,7 @@ struct MpdataArgsT {
   int ntracers;            // x-marching kernels: the 1-D grid is ntracers * groups, tracer fastest
   long long f_tstride;     // elements between consecutive tracers of f
   long long flux_tstride;  // ... of flux
-  unsigned long long* dbg;  // diagnostic builds only (-DMPD2_STAMPS): in-kernel clock stamps; else null
+  unsigned long long* dbg;  // unused by these kernels (the wave-major kernels' diagnostic build has its own: MpdataWmArgsT::dbg)
 };
 typedef MpdataArgsT<double> MpdataArgs;
 typedef MpdataArgsT<float> MpdataArgsF32;

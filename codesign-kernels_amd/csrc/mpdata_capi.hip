@@ -375,10 +375,7 @@ int wm_flags() {
                  (getenv("MPDATA_WM_NOSPLIT") ? MPDATA_WMF_NOSPLIT : 0);
   return g_wm_flags;
 }
-#ifndef MPDWM_WPB
-#define MPDWM_WPB 4
-#endif
-int wm_wpb() { return MPDWM_WPB; }  // waves (tiles) per workgroup of the wave-major kernels
+int wm_wpb() { return 4; }  // waves (tiles) per workgroup of the wave-major kernels
 struct DevGuard {
   int prev = -1, dev;
   explicit DevGuard(int d) : dev(d) {
@@ -1341,8 +1338,9 @@ int mpdata_set_tile(int tile) {
   g_tile = tile < 0 ? -1 : tile;
   return prev;
 }
-// Diagnostic builds (-DMPD2_STAMPS) write s_memtime/s_memrealtime stamps of wave 0 of
-// every workgroup into this device buffer; production builds ignore it.
+// Diagnostic builds (-DMPDWM_STAMPS, tools/wave_timeline.py) write 8 words per wave of the plan kernels into
+// this device buffer (start / end on the 100-MHz counter and the shader clock, cycles in the counted DMA
+// waits, HW_ID, XCC_ID, tile); production builds ignore it.
 int mpdata_set_debug_buffer(void* dev_ptr) {
   g_dbg = (unsigned long long*)dev_ptr;
   return 0;

@@ -148,13 +148,6 @@ __device__ __forceinline__ f32x2 recip_nr(f32x2 d) {
 }
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-// cache-policy bits of the row stores / DMA loads (experiments: 2 = nt)
-#ifndef MPD2_ST_AUX
-#define MPD2_ST_AUX 0
-#endif
-#ifndef MPD2_LD_AUX
-#define MPD2_LD_AUX 0
-#endif
 // Buffer addressing for the row transfers: wave-uniform descriptor + per-lane
 // 32-bit byte offset (VGPR) + wave-uniform byte offset of the column (SGPR).
 // The range (num_records) is clipped BELOW the out-of-range marker 0xFFFFFFF8 the kernel uses
@@ -164,25 +157,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0,
                                            (int)(unsigned)(bytes > lim ? lim : bytes), 0x00020000);
 }
-template <int AUX = MPD2_ST_AUX>
+template <int AUX = 0>
 __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
-#ifdef MPD2_ABL_NOMEM  // timing ablation only (wrong results)
-  if (v != 1.2345e300) return;
-#endif
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, AUX);
 }
 template <int AUX = 0>
 __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x2 v) {
-#ifdef MPD2_ABL_NOMEM
-  if (v.x != 1.2345e30f) return;
-#endif
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
 }
 template <int AUX = 0>
 __device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
-#ifdef MPD2_ABL_NOMEM
-  if (v != 1.2345e30f) return;
-#endif
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
 
@@ -228,11 +212,7 @@ __device__ __forceinline__ R shift_up(R x) { return dpp_mov<MPD_DPP_WAVE_SHL1>(x
 // s_nop 0 are those two.
 // Executed by ALL lanes (under a divergent EXEC mask a switched-off source lane counts as
 // missing).
-#ifdef MPD_DPP_NOP1   // (experiment: the longer wait)
-#define MPD_DPP_NOP "s_nop 1"
-#else
 #define MPD_DPP_NOP "s_nop 0"
-#endif
 #define MPD_CNDMASK_DPP64(CTRL)                                                                \
   int lo, hi;                                                                                  \
   const int xl = __double2loint(x), xh = __double2hiint(x);                                    \
@@ -325,8 +305,8 @@ struct Window {
 template <typename R, int LPS, int G, bool BIG, bool NT = false>
 __global__ void __launch_bounds__(G * LPS, (TileV2<R, LPS, G>::MIN_WAVES))
 mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
-  constexpr int LD_AUX = NT ? 2 : MPD2_LD_AUX;
-  constexpr int ST_AUX = (NT && std::is_same<R, double>::value) ? 2 : (std::is_same<R, double>::value ? MPD2_ST_AUX : 0);
+  constexpr int LD_AUX = NT ? 2 : 0;
+  constexpr int ST_AUX = (NT && std::is_same<R, double>::value) ? 2 : 0;
   using T = TileV2<R, LPS, G>;
   constexpr int RS = T::RS, SLP = T::SLP, RPI = T::RPI;
   constexpr int RB = (int)sizeof(R);  // bytes per element
@@ -346,7 +326,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   const unsigned ntr_ = (unsigned)a.ntracers;
   int tr = (int)(blockIdx.x % ntr_);
   unsigned grp = blockIdx.x / ntr_;
-#ifndef MPD2_NO_XCD_TRACERS
   // Tracer batches: workgroups are dealt to the 8 XCDs round-robin in dispatch order, so with
   // the plain mapping the tracers of one instance group land on 8 different L2s.  Re-deal
   // them: all tracers of group g go to XCD g % 8, back to back, and 24 of 25 reads of that
@@ -361,7 +340,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
       grp = (j / ntr) * nxcd + xcd;
     }
   }
-#endif
   const long long sl_base = (long long)grp * G;
 
   R* const f = a.f + (long long)tr * a.f_tstride;
@@ -494,28 +472,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
     }
   };
 
-#ifdef MPD2_STAMPS
-  // diagnostic build: wave 0 of each workgroup records (shader clock, 100 MHz real time)
-  // at kernel start/end and the shader clock at 4 points of every step
-  unsigned long long* const dbgw = a.dbg ? a.dbg + (size_t)blockIdx.y * 256 : nullptr;
-  const bool stamp = dbgw && wave == 0 && blockIdx.x == 0;
-  int stamp_i = 4;
-  auto STAMP = [&]() __attribute__((always_inline)) {
-    if (stamp && stamp_i < 256) {
-      unsigned long long t;
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-      if (lane == 0) dbgw[stamp_i] = t;
-      ++stamp_i;
-    }
-  };
-  if (stamp) {
-    unsigned long long t0, r0;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
-    if (lane == 0) { dbgw[0] = t0; dbgw[1] = r0; }
-  }
-#else
-#define STAMP() ((void)0)
-#endif
   Window<R> S;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -535,17 +491,14 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
 
     // column q landed (this wave's DMA of it is 2 steps = 14 vector-memory ops
     // old), out tile of column q-4 written: then everyone's are, after the barrier
-    STAMP();
     static_assert(T::NSLOT == 4 && (T::VM_PER_STEP == 7 || T::VM_PER_STEP == 4), "the counted waits below assume them");
     // (only the DMA instructions of the two newer columns may still be outstanding: loads return in
     //  issue order, but a row store may be acknowledged before an older load has landed, so the
     //  stores issued in between must not be counted -- vmcnt(14) / vmcnt(8) would be a race)
     if constexpr (T::VM_PER_STEP == 7) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    STAMP();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    STAMP();
 
 
     // ---- this column, transposed: lanes along k -------------------------------
@@ -618,7 +571,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
     S.UR[C0] = uq;
     S.WR[C0] = wq;
 
-    STAMP();
     // ================= stage B/C ===============================================
     R U2_1 = R(0), U2p_1 = R(0), U2n_1 = R(0), W2_2 = R(0), W2p = R(0), W2n = R(0), MXN_2 = R(0), MNN_2 = R(0);
     if (FULL || (q >= 1 && q <= nx + 3)) {
@@ -809,13 +761,6 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
     }
   }
 
-#ifdef MPD2_STAMPS
-  if (stamp) {
-    unsigned long long t1, r1;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
-    if (lane == 0) { dbgw[2] = t1; dbgw[3] = r1; }
-  }
-#endif
   if (lvl_ok && slc_ok) flux[sl_c + ncrms * (long long)(k - 1)] = S1 + S3;  // :541-547, :624
 }
 

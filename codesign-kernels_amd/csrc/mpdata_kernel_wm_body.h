@@ -49,16 +49,6 @@
 
 #include "mpdata_args.h"
 
-// experiments on the kernel that reads u, w from the reference layout (UWREF): where in a pair the
-// workgroup's u, w fetch is issued (0: behind the barrier, 1: between the pair's two steps, 2: behind
-// the second), cache policy of those fetches (2 = streaming)
-#ifndef MPDWX_UW_POS
-#define MPDWX_UW_POS 1
-#endif
-#ifndef MPDWX_UW_AUX
-#define MPDWX_UW_AUX 2
-#endif
-
 namespace MPDATA_NS {
 namespace wm {
 
@@ -200,38 +190,23 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   // (XNEW, XSUM below: 6 operations per column fewer) in 128 VGPRs.  The registers come from: rho folded into
   // the limiter's reciprocal, one flux accumulator, ONE ring value dW/adz - U per column instead of U and dW
   // (ESUM), the flux position formed again behind the march.  +1 % on the headline (and on fp32); in the u, w-ring form it
-  // spills (-DMPDWM_UW_X: -7 %), and in the two-tracer form ESUM alone costs 1 % (scheduling): both left as they were.
-#if !defined(MPDWM_NO_T1X) && defined(MPDATA_FAST_DIV) && !defined(MPDWM_EXTREMA_OLD)
-#ifdef MPDWM_UW_X
-  constexpr bool T1X = TPW == 1;
+  // spills (-7 %), and in the two-tracer form ESUM alone costs 1 % (scheduling): both left as they were.
+#ifdef MPDATA_FAST_DIV
+  constexpr bool FASTV = true;
 #else
-  constexpr bool T1X = TPW == 1 && !UWREF;
+  constexpr bool FASTV = false;
 #endif
-#else
-  constexpr bool T1X = false;
-#endif
+  constexpr bool T1X = FASTV && TPW == 1 && !UWREF;
   // The u, w-ring form (FAST) takes what fits of it: the merged ring value, the folded rho and the flux position make
   // room for the 7-operation extrema, not for the ring sums (they spill inside the march: -8 %).  +0.5 ... 0.9 %.
-#if defined(MPDATA_FAST_DIV) && !defined(MPDWM_NO_T1X) && !defined(MPDWM_EXTREMA_OLD)
-  constexpr bool UWX2 = UWREF && !T1X;
-#else
-  constexpr bool UWX2 = false;
-#endif
-#ifdef MPDWM_EXTREMA_OLD
-  constexpr bool XNEW = false;
-#else
+  constexpr bool UWX2 = FASTV && UWREF;
   // the 7-operation extrema (stage A below): where the registers allow it (the u, w-ring form with one instance per
   // wave, LPS = 64, and its converting form UWCONV are two registers short: they keep the merged ring value and take
   // the extrema as written)
   constexpr bool XNEW = TPW == 2 || T1X || (UWX2 && LPS < 64 && !UWCONV);
-#endif
   // FAST, two tracers per wave (the VALU- / power-bound form): three operations per tracer and column fewer
   // by carrying sums in the rings and sharing the velocity parts of the upwind fluxes (below: XSUM)
-#if defined(MPDATA_FAST_DIV) && !defined(MPDWM_NO_XSUM)
-  constexpr bool XSUM = XNEW && !UWX2;
-#else
-  constexpr bool XSUM = false;
-#endif
+  constexpr bool XSUM = FASTV && XNEW && !UWX2;
   constexpr bool ESUM = T1X || UWX2;
   // the upwind fluxes (:532, :537): two tracers per wave share the velocity parts max(0,u), min(0,u) (a multiply and
   // an FMA per tracer); one tracer per wave takes the select form (compare, two 32-bit selects, multiply: the same
@@ -494,8 +469,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
       R* d = xring + (P % T::NS) * T::XSLOT + x_dst;
       const int c0 = 2 * P, c1 = 2 * P + 1;
       const bool e0 = c0 >= 1 && c0 <= x_ncols, e1 = c1 <= x_ncols;   // u: c = 1 .. nx+5, w: c = 1 .. nx+4
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(d), 16, (int)(e0 ? xv : OOB), (int)((unsigned)max(c0 - 1, 0) * x_colB), 0, MPDWX_UW_AUX);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(d + 2 * T::XARR), 16, (int)(e1 ? xv : OOB), (int)((unsigned)max(c1 - 1, 0) * x_colB), 0, MPDWX_UW_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(d), 16, (int)(e0 ? xv : OOB), (int)((unsigned)max(c0 - 1, 0) * x_colB), 0, AUX_NT);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(d + 2 * T::XARR), 16, (int)(e1 ? xv : OOB), (int)((unsigned)max(c1 - 1, 0) * x_colB), 0, AUX_NT);
     }
   };
   // interior pairs (1 <= P, 2P+1 <= nx+4): no conditions
@@ -508,9 +483,6 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   // AHEAD = 2: the early store of a halo column c = q + 1.
   auto st_col = [&](const bool act, const int c, const V v, auto ahead_tag) __attribute__((always_inline)) {
     constexpr int AHEAD = decltype(ahead_tag)::value;
-#ifdef MPD2_ABL_NOMEM  // timing ablation only (wrong results)
-    if (__builtin_bit_cast(double, first(v)) != 1.2345e300) return;
-#endif
     const v2::u32x2 b = __builtin_bit_cast(v2::u32x2, first(v));
     if constexpr (UWREF) {   // as STREAM, with ONE offset register: a lane's element lies in one of the two parts
       const unsigned o = act ? st_ab : OOB;
@@ -947,13 +919,11 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     __builtin_amdgcn_s_barrier();                       \
     asm volatile("" ::: "memory");                      \
     MPDWM_FLUSH_DEFERRED                                \
-    if (MPDWX_UW_POS == 0) dma_uw((((q) + 2) >> 1) + 2); \
     step(PHA{}, SL{}, I0{}, TAG{}, (q), in_e);          \
     asm volatile("" ::: "memory");                      \
-    if (MPDWX_UW_POS == 1) dma_uw((((q) + 2) >> 1) + 2); \
+    dma_uw((((q) + 2) >> 1) + 2);   /* (between the two steps; behind the barrier or behind the pair: no better) */ \
     step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1, in_e);      \
     asm volatile("" ::: "memory");                      \
-    if (MPDWX_UW_POS == 2) dma_uw((((q) + 2) >> 1) + 2); \
     DMA((q) + 1);                                       \
   } else if constexpr (TPW == 1) {                      \
     if constexpr (STREAM) MPDWM_WAIT("s_waitcnt vmcnt(12)") \

@@ -73,11 +73,9 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
 // wave-major kernels (mpdata_kernel_wm_body.h, the plan API): LPS = lanes per instance (>= nz),
 // WPB = waves per workgroup.  Returns false if (lps, wpb) is not instantiated.
 #define MPDATA_WM_LPS(X) X(8) X(16) X(32) X(64)
-// waves (= tiles) per workgroup of the plan kernels; the waves of a workgroup never synchronise, the
-// workgroup is only the unit in which the dispatcher hands out wave slots and LDS
-#ifndef MPDWM_WPB
+// waves (= tiles) per workgroup of the plan kernels; the waves of a workgroup never synchronise, the workgroup is
+// only the unit in which the dispatcher hands out wave slots and LDS (1, 2, 4, 8 measured alike, profiles/r04_ablation.json)
 #define MPDWM_WPB 4
-#endif
 template <typename R, int LPS, int WPB>
 static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
   // ntracers == 1: wave = tile in dispatch order, u and w streamed; else the per-XCD tracer walk with
@@ -199,53 +197,14 @@ const char* build_flags() {
 #ifdef MPDWM_ABL_FIRSTPASS
          " MPDWM_ABL_FIRSTPASS"
 #endif
-#ifdef MPD2_ABL_NOMEM
-         " MPD2_ABL_NOMEM"
-#endif
 #ifdef MPD2_ABL_NODMA
          " MPD2_ABL_NODMA"
 #endif
 #ifdef MPD2_ABL_NOCOMPUTE
          " MPD2_ABL_NOCOMPUTE"
 #endif
-#ifdef MPD2_STAMPS
-         " MPD2_STAMPS"
-#endif
 #ifdef MPDWM_STAMPS
          " MPDWM_STAMPS"
-#endif
-#if MPDWM_WPB != 4
-         " MPDWM_WPB"
-#endif
-#ifdef MPD2_NO_XCD_TRACERS
-         " MPD2_NO_XCD_TRACERS"
-#endif
-#ifdef MPD_DPP_NOP1
-         " MPD_DPP_NOP1"
-#endif
-#ifdef MPDWM_EXTREMA_OLD
-         " MPDWM_EXTREMA_OLD"
-#endif
-#ifdef MPDWM_NO_XSUM
-         " MPDWM_NO_XSUM"
-#endif
-#ifdef MPDWM_NO_T1X
-         " MPDWM_NO_T1X"
-#endif
-#ifdef MPDWM_UW_X
-         " MPDWM_UW_X"
-#endif
-#if MPDWX_UW_POS != 1
-         " MPDWX_UW_POS"
-#endif
-#if MPDWX_UW_AUX != 2
-         " MPDWX_UW_AUX"
-#endif
-#if MPD2_ST_AUX != 0
-         " MPD2_ST_AUX"
-#endif
-#if MPD2_LD_AUX != 0
-         " MPD2_LD_AUX"
 #endif
       ;
 }

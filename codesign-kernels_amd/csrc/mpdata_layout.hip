@@ -145,11 +145,8 @@ __global__ void __launch_bounds__(256) wm_convert_cols_kernel(const MpdataLayout
     pstep[e] = pmain[e] ? j.main_e : rem_e;
     pp[e] = prv + po[e] + (long long)j.prv_col0 * pstep[e];
   }
-  // MPD_CONV_DEPTH columns in flight: the fetch of column c + DEPTH goes out before column c + 1 is waited for.
-#ifndef MPD_CONV_DEPTH
-#define MPD_CONV_DEPTH 2
-#endif
-  constexpr int DEPTH = MPD_CONV_DEPTH;
+  // DEPTH columns in flight: the fetch of column c + DEPTH goes out before column c + 1 is waited for.
+  constexpr int DEPTH = 2;
   R vs[DEPTH][NPT];
   auto fetch = [&](R (&v)[NPT]) {   // the column the source pointers stand on; then on to the next
 #pragma unroll
@@ -305,8 +302,7 @@ hipError_t mpdata_layout_convert_cols(const MpdataLayoutJob* jobs, int nj, bool 
   const int nlev = jobs[0].nlev;
   // instances per workgroup: 8 elements per thread and column
   // (an export is 7 % faster with twice as many, half as wide workgroups; an import is not)
-  static const int ti_env = [] { const char* v = getenv("MPDATA_CONV_TI"); return v ? atoi(v) : 0; }();   // (experiments: 32 / 64)
-  const int ti = ti_env == 32 || (ti_env == 0 && !to_private) ? 32 : (nlev * 64 <= 2048 ? 64 : 32);
+  const int ti = !to_private ? 32 : (nlev * 64 <= 2048 ? 64 : 32);
   const dim3 grid((unsigned)((nc + ti - 1) / ti), 1, (unsigned)(nj * js.ntr_max)), block(256);
   const size_t lds = (size_t)2 * nlev * (ti + 1) * 8;
   if (ti == 64) {

@@ -130,9 +130,7 @@ __global__ void __launch_bounds__(64 * NLK_WAVES) nlk_kernel(const NlkArgs g) {
 // lanes, 13 vector-memory instructions per edge instead of 26.  Needs even nvldim and 16-byte aligned
 // arrays (else the kernel above).  The range check of a raw buffer descriptor is per dword, so a level
 // range that ends between a lane's two levels still masks exactly.
-#ifndef NLK_CH2
 #define NLK_CH2 10  // cells per batch of the two-levels-per-lane kernel (32 x mesh, local connectivity: 5 -> 0.83 ms, 10 -> 0.75 ms)
-#endif
 typedef unsigned int nlk_u32x4 __attribute__((ext_vector_type(4)));
 typedef double nlk_f64x2 __attribute__((ext_vector_type(2)));
 

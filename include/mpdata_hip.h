@@ -268,7 +268,7 @@ int mpdata_set_serpentine(int on);
  * set the initial value); flags < 0 only queries.  Returns the previous value. */
 int mpdata_set_wm_flags(int flags);
 int mpdata_set_tile(int tile);            /* kernel tiling id; -1 = default */
-int mpdata_set_debug_buffer(void* dev_ptr); /* diagnostic builds only: clock-stamp buffer */
+int mpdata_set_debug_buffer(void* dev_ptr); /* diagnostic builds only (-DMPDWM_STAMPS): per-wave stamp buffer */
 int mpdata_device_count(void);
 int64_t mpdata_algorithmic_bytes(int64_t ncrms, int nx, int nz, int ntracers);
 /* Diagnostic: GB/s this GPU sustains for the routine's traffic mix (3 arrays read, 1 written in
