@@ -110,6 +110,14 @@ namespace {
     if (rc_) return rc_;       \
   } while (0)
 
+// MPDATA_MULTI_SYNC=1: synchronise every stream after EVERY array of a scatter / gather (the round-2
+// behaviour) instead of once per transfer.  A fallback for bring-up on real multi-GPU nodes: the default
+// ordering -- per-array stream order and events, no host synchronisation in between -- has run against the
+// recording RCCL stand-in, with peer copies on one device and with one real RCCL rank, never yet on xGMI.
+bool sync_each_array() {
+  static const bool on = getenv("MPDATA_MULTI_SYNC") != nullptr;
+  return on;
+}
 // MPDATA_MULTI_TRACE=1: one stderr line per step of scatter / gather (diagnosis of stalls)
 bool trace_on() {
   static const bool on = getenv("MPDATA_MULTI_TRACE") != nullptr;
@@ -225,6 +233,7 @@ int scatter_array(mpdata_multi* m, int which, const void* src, bool host_origin,
                              (size_t)m->ncrms * eb, (size_t)m->nloc[g] * eb, rows, hipMemcpyHostToDevice, m->stream[g]));
       M_TRY(import_block(m, g, which, tracer));
     }
+    if (sync_each_array()) M_TRY(sync_all(m));
     return 0;
   }
   // through the root: (host arrays: full-width copy in, on the copy stream, into the staging buffer
@@ -268,6 +277,7 @@ int scatter_array(mpdata_multi* m, int which, const void* src, bool host_origin,
     M_HIP(hipSetDevice(m->dev[g]));
     M_TRY(import_block(m, g, which, tracer));
   }
+  if (sync_each_array()) M_TRY(sync_all(m));
   return 0;
 }
 
@@ -288,6 +298,7 @@ int gather_array(mpdata_multi* m, int which, void* dst, bool host_origin, int tr
       M_HIP(hipMemcpy2DAsync((char*)dst + (size_t)m->sl0[g] * eb, (size_t)m->ncrms * eb, m->rb[g], (size_t)m->nloc[g] * eb,
                              (size_t)m->nloc[g] * eb, rows, hipMemcpyDeviceToHost, m->stream[g]));
     }
+    if (sync_each_array()) M_TRY(sync_all(m));
     return 0;
   }
   if (xf == XFER_RCCL) {
@@ -309,6 +320,7 @@ int gather_array(mpdata_multi* m, int which, void* dst, bool host_origin, int tr
   if (xf == XFER_P2P)
     for (int g = 1; g < G; ++g) M_HIP(hipEventRecord(m->ga_unpacked[g], m->stream[0]));
   if (host_origin) M_HIP(hipMemcpyAsync(dst, full, rows * (size_t)m->ncrms * eb, hipMemcpyDeviceToHost, m->stream[0]));
+  if (sync_each_array()) M_TRY(sync_all(m));
   return 0;
 }
 

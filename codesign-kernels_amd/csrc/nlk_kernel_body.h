@@ -286,11 +286,15 @@ __global__ void __launch_bounds__(64 * NLK_WAVES) nlk_kernel_x2v(const NlkArgs g
     wgt[0] = ntf.x * msk.x; wgt[1] = ntf.y * msk.y;                                        // :126-127
     sgn[0] = __builtin_copysign(1.0, ntf.x); sgn[1] = __builtin_copysign(1.0, ntf.y);      // :128-129
     constexpr int CH = NLK_CH2;
-    for (int i0 = 0; i0 < nadv; i0 += CH) {                                                // :136-148
+    // a batch of CH cells i0 .. i0+CH-1.  FULL: all of them exist (the usual case: every edge of the reference's
+    // mesh has nAdv cells) -- no guards: the `i < nadv` compares, selects and branches of the guarded form were 8 of
+    // the ~10 scalar instructions per gather on the CU's one scalar unit (round 4: the nest is scalar-issue bound)
+    auto batch = [&](const int i0, auto full_tag) __attribute__((always_inline)) {
+      constexpr bool FULL = decltype(full_tag)::value;
       double tv[CH][2];
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
-        const bool have = i0 + j < nadv;       // (wave-uniform; a missing cell: empty range, reads zeros)
+        const bool have = FULL || i0 + j < nadv;       // (wave-uniform; a missing cell: empty range, reads zeros)
         const int jj = have ? i0 + j : 0;
         const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)cbv, jj);
         const unsigned nrec = have ? (unsigned)__builtin_amdgcn_readlane((int)nrecv, jj) : 0u;
@@ -301,19 +305,26 @@ __global__ void __launch_bounds__(64 * NLK_WAVES) nlk_kernel_x2v(const NlkArgs g
       if (any_kmin) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-          const int kmin = __builtin_amdgcn_readlane(kminv, i0 + j < nadv ? i0 + j : 0);
+          const int kmin = __builtin_amdgcn_readlane(kminv, (FULL || i0 + j < nadv) ? i0 + j : 0);
           tv[j][0] = kA >= kmin ? tv[j][0] : 0.0;
           tv[j][1] = kB >= kmin ? tv[j][1] : 0.0;
         }
       }
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
-        const int jj = i0 + j < nadv ? i0 + j : 0;
+        const int jj = (FULL || i0 + j < nadv) ? i0 + j : 0;
         const double c1 = rl_d(c1v, jj), c3 = rl_d(c3v, jj);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = acc[t] + tv[j][t] * wgt[t] * (c1 + c3 * sgn[t]);
+        for (int t = 0; t < 2; ++t) acc[t] = acc[t] + tv[j][t] * wgt[t] * (c1 + c3 * sgn[t]);   // :136-148
       }
+    };
+    int i0 = 0;
+    if (nadv == CH) {   // (the reference's own shape: one batch, lane indices known at compile time)
+      batch(0, std::true_type{});
+      i0 = CH;
     }
+    for (; i0 + CH <= nadv; i0 += CH) batch(i0, std::true_type{});
+    if (i0 < nadv) batch(i0, std::false_type{});
     if (lB) *reinterpret_cast<nlk_f64x2*>(g.highOrderFlx + erow + kA - 1) = nlk_f64x2{acc[0], acc[1]};
     else if (lA) g.highOrderFlx[erow + kA - 1] = acc[0];
   }

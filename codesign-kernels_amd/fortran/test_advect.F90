@@ -29,7 +29,9 @@
 !! format the reference executable built by oracle/build_ref.py dumps) and
 !! prints the reference's two "Relative L1 Error" lines (:681-682);
 !! tests/test_fortran_driver.py feeds it the oracle's result.  `dumpfile` / `reffile`
-!! may be `-` to skip.
+!! may be `-` to skip.  Without any file the host mode still validates itself: its drop-in call and its
+!! resident run go through two independent kernel families of the library, and the program prints the
+!! same two lines for one against the other ("Self-check").
 program test_advect
   use iso_c_binding
   use mpdata_grid
@@ -37,7 +39,7 @@ program test_advect
   implicit none
 
   real(rp), allocatable :: f(:,:,:,:,:), u(:,:,:,:), w(:,:,:,:), rho(:,:), rhow(:,:), flux(:,:,:)
-  real(rp), allocatable :: f_in(:,:,:,:,:)
+  real(rp), allocatable :: f_in(:,:,:,:,:), f_call(:,:,:,:,:), flux_call(:,:,:)
   integer(c_int64_t) :: n_arg
   integer :: nx_arg, nz_arg, dist, variant, rc, nt_arg, ng_arg, ranks
   character(len=512) :: arg, dumpfile, reffile
@@ -126,6 +128,8 @@ contains
   call print_transfer_stats()
   call save()
   call compare()
+  allocate(f_call, source=f)          ! (kept for the in-program self-check below)
+  allocate(flux_call, source=flux)
 
   ! ---- device-resident: the reference's timed region (kernels only, :110-:238)
   call init()
@@ -144,6 +148,14 @@ contains
   write(*,*) 'cell updates per call: ', nslices*int(nx,8)*int(nzm,8)*int(ntracers,8)
   write(*,*) 'checksum f   : ', sum(f)
   write(*,*) 'checksum flux: ', sum(flux(:,1:nzm,:))
+  ! ---- in-program self-check, the reference's `init -> variant -> compare` (:52-58) without a CPU routine:
+  !      the drop-in call above and the resident run just finished go through two INDEPENDENT kernel families
+  !      of the library (reference-layout x-march kernel / plan-layout wave-major kernel, different lane
+  !      mappings, data paths and summation trees) on the same init() data.  EXACT: f must agree bit for bit
+  !      (0.0), flux to rounding; FAST: both to rounding.
+  write(*,*) 'Self-check (host-call kernel vs resident-plan kernel):'
+  write(*,*) 'Relative L1 Error - f    : ' , sum(abs( f    - f_call    )) / sum(abs( f_call    ))
+  write(*,*) 'Relative L1 Error - flux : ' , sum(abs( flux(:,1:nzm,:) - flux_call(:,1:nzm,:) )) / sum(abs( flux_call(:,1:nzm,:) ))
   end subroutine run_host_mode
 
   !> the namelist form of the command line; names as in BASELINE.json / the C-ABI.  Values not

@@ -33,7 +33,10 @@ def test_product_library_links_rccl_not_the_stand_in():
 
 
 @pytest.mark.gpu
-def test_rccl_branch_with_several_ranks_on_one_device():
+@pytest.mark.parametrize("sync_each", [False, True], ids=["queued", "sync-after-every-array"])
+def test_rccl_branch_with_several_ranks_on_one_device(sync_each):
+    """sync_each: MPDATA_MULTI_SYNC=1, the bring-up fallback that synchronises every stream after every array of
+    a transfer instead of once per transfer (same groups, same results)."""
     if not os.path.exists(FAKE_LIB):
         import shutil
         if not shutil.which("hipcc"):
@@ -42,6 +45,9 @@ def test_rccl_branch_with_several_ranks_on_one_device():
                        stdout=subprocess.DEVNULL)
     env = dict(os.environ, MPDATA_HIP_LIB=FAKE_LIB, MPDATA_MULTI_FORCE_RCCL="1")
     env.pop("MPDATA_MULTI_XFER", None)
+    env.pop("MPDATA_MULTI_SYNC", None)
+    if sync_each:
+        env["MPDATA_MULTI_SYNC"] = "1"
     r = subprocess.run([sys.executable, os.path.join(STUBS, "run_fake_rccl_case.py")], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
