@@ -4,6 +4,7 @@ against the oracle -- the compare() step of the reference's driver
 (mmf-mpdata-tracer/advect_scalar2D_pushncols_openacc.F90:679-683), done here
 because the product driver carries no CPU advection routine."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -143,7 +144,7 @@ def test_driver_tracers_and_gpus(oracle, tmp_path, ntr, ngpus, use_nml):
     s1 = re.search(r"Relative L1 Error - f\s*:\s*([0-9.Ee+-]+)", sc)
     s2 = re.search(r"Relative L1 Error - flux\s*:\s*([0-9.Ee+-]+)", sc)
     assert s1 and s2, sc
-    assert float(s1.group(1)) == (0.0 if variant == 0 else pytest.approx(0.0, abs=1e-14))
+    assert float(s1.group(1)) == 0.0   # (EXACT)
     assert float(s2.group(1)) < 1e-13
     raw = np.fromfile(dump, dtype=np.float64)
     f = raw[:f_ref.size].reshape(f_ref.shape, order="F")
