@@ -567,7 +567,14 @@ def bench_fresh_uw(M, torch, dist_mod, world, dev, shared, shape_f, n_loc, n_glo
             sets.append((pl, None, None))
             pl.set_stream()
             pl.set_timing(False)
-            u = torch.empty_like(shared["u"]); w = torch.empty_like(shared["w"])
+            # (u, w placed as every reference-layout array of this bench is: bases at different offsets modulo
+            #  1 KiB -- INTEGRATION.md 6; two plain 2-MiB-aligned allocations put the row streams of u and w on
+            #  the same HBM channels, 7 % slower)
+            if ALIGNED:
+                u = torch.empty_like(shared["u"]); w = torch.empty_like(shared["w"])
+            else:
+                u = M.empty_staggered(tuple(shared["u"].shape), "u", tdt, dev)
+                w = M.empty_staggered(tuple(shared["w"].shape), "w", tdt, dev)
             M.fill_synthetic(u, "u", 500 + 31 * s_, dist_law, ncrms_global=n_glob, sl0=sl0)
             M.fill_synthetic(w, "w", 500 + 31 * s_, dist_law, ncrms_global=n_glob, sl0=sl0)
             M.fill_synthetic(ftmp, "f", 500 + s_, dist_law, ncrms_global=n_glob, sl0=sl0)

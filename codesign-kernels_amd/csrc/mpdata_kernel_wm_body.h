@@ -398,8 +398,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   //  pair issued -- pairs are issued in order --, the store offset by its column stride with every
   //  column step; lanes that own nothing keep the out-of-range marker: stride 0)
   unsigned dcur = lane_main ? vA : vB;
-  // (UWREF: ONE register for both branches of the f fetch -- seen as a select of vA / vB the compiler keeps both)
-  if constexpr (UWREF) asm volatile("" : "+v"(dcur));
+  // (the register-starved forms of the u, w-ring kernel: ONE register for both branches of the f fetch -- seen as a
+  //  select of vA / vB the compiler keeps both)
+  if constexpr (UWREF && (LPS == 64 || UWCONV)) asm volatile("" : "+v"(dcur));
   // the two per-lane strides share one register: pair stride of the lane's DMA part in the low
   // half, column stride of its store part in the high half (both <= 1024); a stride is added with
   // the half-word select of the add itself (SDWA), so unpacking costs no instruction
