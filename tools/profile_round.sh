@@ -2,11 +2,13 @@
 # Round profile: kernel-trace stats + separate PMC passes of the headline bench (1 tracer, plan
 # API, wave-major layout) and of the 25-tracer batch, then tools/pmc_summary.py writes the
 # summaries the judge reads into profiles/.
-#   usage (on the GPU box):  bash tools/profile_round.sh r03   (tools/record_round.sh runs it with the other records of a round)
+#   usage (on the GPU box):  bash tools/profile_round.sh r04   (tools/record_round.sh runs it with the other records of a round)
+# The wake-up launches of bench.py cycle through its scratch field sets (round 4): every dispatch of the kernel trace is a
+# cold one, the CSV's plain average is the cold figure.
 # rocprofv3 rules of this pool: the program itself after `--`; --pmc never together with
 # --kernel-trace/--stats; one counter group per pass.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT

@@ -1,12 +1,12 @@
 #!/bin/bash
-# The records of a round, on the GPU box:  bash tools/record_round.sh r03
+# The records of a round, on the GPU box:  bash tools/record_round.sh r04
 #   gpurun_out/<tag>_final/bench_driver.json   bench.py with the driver's arguments (--steps 20 --warmup 5)
 #   gpurun_out/<tag>_final/bench_default.json  bench.py with its defaults (100 + 100 launches)
 #   gpurun_out/<tag>_final/fortran_driver.txt  the Fortran driver: host mode (1 tracer), device mode (25 tracers),
 #                                              ngpus = 1 through the multi-GPU path, 2 shards on one device
 #   gpurun_out/prof_<tag>/                      tools/profile_round.sh (rocprofv3 kernel trace + PMC passes)
 # then here: python tools/pmc_summary.py <tag>; copy the records into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/${TAG}_final
 mkdir -p $OUT
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; echo "bench driver rc=$?"
@@ -28,4 +28,5 @@ F=codesign-kernels_amd/fortran/advect
   $F $OUT/case.nml
 } > $OUT/fortran_driver.txt 2>&1
 echo "fortran rc=$?"
-timeout -k 10 700 bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1; echo "profile rc=$?"
+# the profile passes take ~10 minutes: a gpurun call of their own (PROFILE=0 skips them here)
+if [ "${PROFILE:-1}" = 1 ]; then timeout -k 10 1000 bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1; echo "profile rc=$?"; fi
