@@ -1,4 +1,4 @@
-"""The recorded bench line (profiles/r03_bench.json, written by bench.py on an MI355X) carries what
+"""The recorded bench line (profiles/r04_bench.json, written by bench.py on an MI355X) carries what
 the measurement contract asks for: the headline keys, the `roofline` object of the dominant kernel
 and the `cpu_baseline` object, with consistent arithmetic.  CPU-only: it reads the committed record."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _record():
-    with open(os.path.join(ROOT, "profiles", "r03_bench.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r04_bench.json")) as fh:
         return json.loads(fh.read().strip().splitlines()[-1])
 
 
@@ -56,6 +56,17 @@ def test_tracer_batch_block_reports_both_ceilings():
     assert 0 < r["hbm_frac"] < 1 and 0 < r["valu_frac"] < 1.2
     # BT = 8 nzm (T (2 nx + 11) + 2 nx + 12) per instance
     assert r["algorithmic_bytes_per_launch"] == 65536 * 8 * 27 * (25 * (2 * 32 + 11) + 2 * 32 + 12)
+
+
+def test_no_block_of_the_record_failed_and_the_wake_up_is_cold():
+    d = _record()
+    for k, v in d.items():
+        if isinstance(v, dict):
+            assert "error" not in v, (k, v.get("error"))
+    assert "cycle through the scratch field sets" in d["config"]["prewarm"]
+    lc = d["layout_conversion"]
+    # round 4: the import by row segments through LDS-DMA (round 3: 0.28-0.30 / 0.51-0.54 ms)
+    assert lc["import_ms_f_per_tracer"] <= 0.23 and lc["import_ms_u_and_w"] <= 0.45
 
 
 def test_side_blocks_of_round_3():
