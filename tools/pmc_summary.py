@@ -134,8 +134,9 @@ summary["t1_wavemajor"] = {
     "ratio_traffic_over_algorithmic": (rd + wr) / alg_bytes(1),
     "algorithmic_GBs_at_kernel_trace_avg": alg_bytes(1) / kt["avg_ns"],
     # since round 4 EVERY dispatch of the profiled bench run is cold (the wake-up launches cycle through the scratch field
-    # sets too): the plain average of the kernel trace is the figure; the last 40 dispatches (warm-up, timed and per-launch
-    # passes) are kept as a cross-check
+    # sets too), so the plain average of the kernel trace no longer flatters the kernel -- it now UNDERSTATES the timed
+    # region: it contains the ~150 wake-up launches that absorb the clock / power-state ramp after idle (0.40-0.43 ms
+    # each).  The last 40 dispatches are the warm-up, timed and per-launch passes of bench.py.
     "frac_of_8TBs": alg_bytes(1) / kt["avg_ns"] / 8000.0,
     "frac_of_8TBs_last40_dispatches": alg_bytes(1) / kt.get("mean_last40_ns", kt["avg_ns"]) / 8000.0,
     "sq_per_wave": {c: v / waves for c, v in sq.items() if c != "SQ_WAVES"}, "waves": waves,
