@@ -46,6 +46,8 @@ struct MpdataWmArgsT {
   const R* u_ref;          // u(ncrms, nx+5, nzm)
   const R* w_ref;          // w(ncrms, nx+4, nz)
   long long ncrms;         // leading dimension of u_ref, w_ref
+  R* wpark;                // EXACT only, may be null: park array of the limited vertical fluxes [tracer][tile][nx][64]
+                           // (bit-identical flux: the finishing kernel adds them in the reference's order)
   unsigned long long* dbg; // diagnostic builds only (-DMPDWM_STAMPS): 8 words per wave (tools/wave_timeline.py); else null
 };
 typedef MpdataWmArgsT<double> MpdataWmArgs;

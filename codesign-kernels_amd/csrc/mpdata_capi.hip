@@ -15,6 +15,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 
 #include "mpdata_args.h"
 #include "mpdata_hip.h"
@@ -196,6 +197,34 @@ __global__ void pack_kernel(const double* full, double* shard, long long rows, l
   }
 }
 
+// EXACT, bit-identical flux: the plan kernels store the upwind sum as flux and PARK the nx limited vertical fluxes of
+// every lane ([tracer][tile][column][lane], mpdata_kernel_wm_body.h); this adds them, one by one in the reference's
+// order i = 1 .. nx (:624), onto that sum.  A wave per (tracer, tile), lane -> (instance, level) as in the kernels.
+// R2 = double, or float2 for fp32 plans (two adjacent instances per lane; no contraction: this file is built with
+// -ffp-contract=off).
+template <typename R2>
+__global__ void __launch_bounds__(256) flux_finish_kernel(R2* flux, const R2* park, int ntiles, int nx, int nzm, int lps,
+                                                          long long flux_tstride, int ntr) {
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // wave = tracer * ntiles + tile
+  if (w >= (long long)ntr * ntiles) return;
+  const int tr = (int)(w / ntiles), tile = (int)(w % ntiles);
+  const int s_l = lane / lps, kk = lane % lps;
+  if (kk >= nzm) return;
+  const int chunk = (64 / lps) * nzm;
+  R2* fp = flux + (long long)tr * flux_tstride + (long long)tile * chunk + s_l * nzm + kk;
+  const R2* pp = park + w * ((long long)nx * 64) + lane;
+  R2 acc = *fp;
+  for (int i = 0; i < nx; ++i) {
+    const R2 t = pp[(long long)i * 64];
+    if constexpr (sizeof(R2) == 8 && alignof(R2) == 8 && !std::is_same<R2, double>::value) { acc.x = acc.x + t.x; acc.y = acc.y + t.y; }
+    else acc = acc + t;
+  }
+  *fp = acc;
+}
+
+// the kernel launch(es) of one run of a single-device plan, on the plan's stream
+// (u_ref, w_ref != null: the kernel that reads u, w from these reference-layout arrays)
 unsigned grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
   const long long cap = 256 * 8;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -375,7 +404,13 @@ int wm_flags() {
                  (getenv("MPDATA_WM_NOSPLIT") ? MPDATA_WMF_NOSPLIT : 0);
   return g_wm_flags;
 }
-int wm_wpb() { return 4; }  // waves (tiles) per workgroup of the wave-major kernels
+int wm_wpb() { return 4; }
+// EXACT plans: flux bit-identical to the reference (the limited vertical fluxes parked and added in the reference's
+// order) unless MPDATA_EXACT_FLUX=sum
+bool exact_flux_in_order() {
+  static const bool sum = getenv("MPDATA_EXACT_FLUX") && !strcmp(getenv("MPDATA_EXACT_FLUX"), "sum");
+  return !sum;
+}  // waves (tiles) per workgroup of the wave-major kernels
 struct DevGuard {
   int prev = -1, dev;
   explicit DevGuard(int d) : dev(d) {
@@ -407,6 +442,8 @@ struct mpdata_plan {
   void* stage;                       // reference-layout staging: one tracer of f (or u, w)
   size_t stage_elems;
   void* flux_ref;                    // flux in the reference layout (level nz is carried through)
+  void* wpark;                       // EXACT: park array of the limited vertical fluxes (bit-identical flux), lazily allocated
+  size_t wpark_bytes;
   hipStream_t stream;
   bool own_stream;
   hipEvent_t ev0, ev1;
@@ -660,6 +697,19 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
     if (e == hipSuccess) e = hipMalloc(&p->pkc, (size_t)p->ntiles * 3 * p->chunk * web);
     if (e == hipSuccess) e = hipMalloc(&p->pflux, (size_t)p->ntiles * p->chunk * ntracers * web);
     if (e == hipSuccess) e = hipMalloc(&p->flux_ref, p->sz.kz * ntracers * eb);
+    // EXACT: the park array of the limited vertical fluxes (bit-identical flux, see plan_flux_finish): [tracer][tile][nx][64]
+    // 8-byte elements, the size of f's interior.  MPDATA_EXACT_FLUX=sum does without it (flux = upwind sum + limited sum,
+    // <= 1e-13 relative, the behaviour up to round 3; a quarter faster in the EXACT variant).
+    if (e == hipSuccess && var == MPDATA_VARIANT_EXACT && exact_flux_in_order()) {
+      p->wpark_bytes = (size_t)ntracers * p->ntiles * (size_t)nx * 64 * 8;
+      e = hipMalloc(&p->wpark, p->wpark_bytes);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        mpdata_plan_destroy(p);
+        return set_err((int)e, "mpdata_plan_create (EXACT): no memory for the %.1f-GB park array of the bit-identical flux; "
+                               "MPDATA_EXACT_FLUX=sum does without it (flux then equal to 1e-13 relative)", p->wpark_bytes / 1e9);
+      }
+    }
     // flux: level nz and tracers that are never run export what was imported -- or zeros
     if (e == hipSuccess) e = hipMemset(p->flux_ref, 0, p->sz.kz * ntracers * eb);
     if (e == hipSuccess) e = hipMemset(p->pflux, 0, (size_t)p->ntiles * p->chunk * ntracers * web);
@@ -766,8 +816,21 @@ int mpdata_plan_export_device(mpdata_plan* p, void* f, void* flux, int first_tra
   return plan_export(p, f, flux, first_tracer, ntracers, true);
 }
 
-// the kernel launch(es) of one run of a single-device plan, on the plan's stream
-// (u_ref, w_ref != null: the kernel that reads u, w from these reference-layout arrays)
+// (EXACT wave-major runs: the finishing kernel of the bit-identical flux, behind the plan kernels on the same stream)
+static int plan_flux_finish(mpdata_plan* p, const MpdataWmArgs& a, int count) {
+  if (!a.wpark) return 0;
+  const long long waves = (long long)count * p->ntiles;
+  const unsigned blocks = (unsigned)((waves + 3) / 4);
+  if (p->eb == 8)
+    hipLaunchKernelGGL(flux_finish_kernel<double>, dim3(blocks), dim3(256), 0, p->stream, a.flux, (const double*)a.wpark, p->ntiles,
+                       p->nx, p->nz - 1, p->lps, a.flux_tstride, count);
+  else
+    hipLaunchKernelGGL(flux_finish_kernel<float2>, dim3(blocks), dim3(256), 0, p->stream, (float2*)a.flux, (const float2*)a.wpark,
+                       p->ntiles, p->nx, p->nz - 1, p->lps, a.flux_tstride, count);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // (uw_conv: that kernel also writes the velocities into the plan's own u, w)
 static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref = nullptr, const void* w_ref = nullptr,
                        bool uw_conv = false) {
@@ -784,6 +847,8 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
     a.reverse = serpentine() ? (int)(p->runs++ & 1u) : 0;
     a.u_ref = (const double*)u_ref; a.w_ref = (const double*)w_ref; a.ncrms = p->ncrms;
     a.dbg = g_dbg;   // (null unless a diagnostic build was handed a stamp buffer)
+    // EXACT plans: the park array of the limited vertical fluxes (bit-identical flux; allocated with the plan)
+    a.wpark = p->wpark ? (double*)p->wpark + (long long)first * p->ntiles * ((long long)p->nx * 64) : nullptr;
     const bool fast = p->variant == MPDATA_VARIANT_FAST;
     if (u_ref) {
       a.reverse = 0;
@@ -791,7 +856,7 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
                             : mpdata_exact::launch_wm_uw(p->lps, a, (void*)p->stream, uw_conv);
       if (!okx) return set_err(MPDATA_EINVAL, "wave-major u,w-reference kernel LPS=%d not instantiated", p->lps);
       HIP_TRY(hipGetLastError());
-      return 0;
+      return plan_flux_finish(p, a, count);
     }
     const int fl = wm_flags();
     const bool ok = p->eb == 8 ? (fast ? mpdata_fast::launch_wm(p->lps, p->wpb, a, (void*)p->stream, fl)
@@ -800,6 +865,8 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
                                        : mpdata_exact::launch_wm_f32(p->lps, p->wpb, a, (void*)p->stream, fl));
     if (!ok) return set_err(MPDATA_EINVAL, "wave-major kernel LPS=%d WPB=%d not instantiated", p->lps, p->wpb);
     HIP_TRY(hipGetLastError());
+    rc = plan_flux_finish(p, a, count);
+    if (rc) return rc;
   } else {
     const size_t f1 = p->sz.f / p->ntracers;
     // (the plan's own variant, passed explicitly: the global one may be changed by other threads)
@@ -1035,7 +1102,7 @@ int mpdata_plan_destroy(mpdata_plan* p) {
   }
   DevGuard g(p->device);
   arena_free(p->arena);
-  void* bufs[7] = {p->pf, p->pu, p->pw, p->pkc, p->pflux, p->stage, p->flux_ref};
+  void* bufs[8] = {p->pf, p->pu, p->pw, p->pkc, p->pflux, p->stage, p->flux_ref, p->wpark};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (p->ev0) (void)hipEventDestroy(p->ev0);

@@ -330,6 +330,26 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   // (UWREF: u, w of the plan are not read; UWCONV writes them)
   const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : tileB);
   const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : tileB);
+  // EXACT with a park array (a.wpark != null): bit-identical flux.  The reference adds the limited vertical fluxes
+  // ONE BY ONE onto the finished upwind sum (:545, :624), and the first of them exists 30 columns before that sum is
+  // complete: every lane parks its nx limited fluxes in [tracer][tile][column 1..nx][lane] (one 512-byte row per wave
+  // and column step), stores the upwind sum alone as flux, and a finishing kernel (mpdata_capi.hip: flux_finish_kernel)
+  // adds the parked terms in the reference's order.  FAST never parks (its flux is a sum in another order anyway).
+  constexpr bool CAN_PARK = !FASTV;
+  [[maybe_unused]] const bool park = CAN_PARK && a.wpark != nullptr;
+  [[maybe_unused]] const long long parkB = (long long)nx * 64 * RB;   // bytes of one (tracer, tile) block
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsp = v2::make_rsrc(
+      a.wpark + ((long long)tr * a.ntiles + tile) * ((long long)nx * 64), (park && tile_ok) ? parkB : 0);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsp1 = v2::make_rsrc(
+      a.wpark + ((long long)(tr + 1) * a.ntiles + tile) * ((long long)nx * 64), (park && has1) ? parkB : 0);
+  [[maybe_unused]] auto park_st = [&](const int col, const V w3) __attribute__((always_inline)) {   // col = 1 .. nx
+    unsigned z;   // (the lane's byte offset formed from the execution mask here: no register carries it through the march)
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    const unsigned lo = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)) * (unsigned)RB;
+    const unsigned so = (unsigned)(col - 1) * (64u * RB);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2::u32x2, first(w3)), rsp, (int)lo, (int)so, 0);
+    if constexpr (TPW == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2::u32x2, second(w3)), rsp1, (int)lo, (int)so, 0);
+  };
   // ---- UWREF: u, w in the reference layout (sl fastest, :33-38): u(ncrms, nx+5, nzm), w(ncrms, nx+4, nz).
   //      Row (column c, level kk) of the workgroup = 16 instances = 128 bytes at
   //        ((c-1) + ncols*kk) * ncrms*8 + sl_base*8          (u, w have no column c = 0).
@@ -847,7 +867,8 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         const V mxd = DN_C(MXN_2);
         const V mnd = DN_C(MNN_2);
         const V W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
-        if constexpr (UWREF || T1X) S1 = S1 + W3;  // one accumulator (two registers that kernel does not have)
+        if (CAN_PARK && park) park_st(q - 2, W3);   // (EXACT, bit-identical flux: added behind the march, in order)
+        else if constexpr (UWREF || T1X) S1 = S1 + W3;  // one accumulator (two registers that kernel does not have)
         else S3 = S3 + W3;  // :624
         DW3_2 = UP_G(W3) - W3;
       }
@@ -996,7 +1017,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 
   if constexpr (TPW == 1) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
   {  // flux (:541-547, :624)
-    const V fl = (UWREF || T1X) ? S1 : S1 + S3;
+    const V fl = ((UWREF || T1X) || (CAN_PARK && park)) ? S1 : S1 + S3;   // (parked: the upwind sum alone)
     int posf = pos;
     bool okf = lvl_ok;
     if constexpr (T1X || UWX2) {   // the lane's element, formed again behind the march: no register carries it through

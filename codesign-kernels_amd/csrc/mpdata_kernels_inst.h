@@ -117,6 +117,7 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
       MpdataWmArgsT<R> c = a;
       c.f = a.f + (long long)(a.ntracers - 1) * a.f_tstride;
       c.flux = a.flux + (long long)(a.ntracers - 1) * a.flux_tstride;
+      if (a.wpark) c.wpark = a.wpark + (long long)(a.ntracers - 1) * a.ntiles * ((long long)a.nx * 64);
       c.ntracers = 1;
       const unsigned blocks1 = (unsigned)((c.ntiles + WPB - 1) / WPB);
       hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, true>), dim3(blocks1), dim3(64 * WPB), 0,
@@ -172,6 +173,7 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   a.ntiles = a8.ntiles; a.nx = a8.nx; a.nz = a8.nz; a.ntracers = a8.ntracers;
   a.tile_elems = a8.tile_elems; a.f_tstride = a8.f_tstride; a.flux_tstride = a8.flux_tstride; a.reverse = a8.reverse;
   a.u_ref = nullptr; a.w_ref = nullptr; a.ncrms = 0; a.dbg = a8.dbg;
+  a.wpark = reinterpret_cast<v2::f32x2*>(a8.wpark);
 #define X(LPS_)                                \
   if (lps == LPS_) {                           \
     launch_wm_t<v2::f32x2, LPS_, MPDWM_WPB>(a, stream, flags); \

@@ -168,7 +168,8 @@ def test_fp32_host_dropin_call(M, oracle):
     f2, flux2 = np.empty_like(f), np.empty_like(flux)
     plan.download(f2, flux2)
     plan.close()
-    assert np.array_equal(f2, f_ref) and flux_close(flux2, flux_ref)
+    # (an fp32 PLAN with an even ncrms runs the wave-major kernels: flux bit-identical too since round 4)
+    assert np.array_equal(f2, f_ref) and np.array_equal(flux2, flux_ref)
     with pytest.raises(M.MpdataError):  # mixed precisions are refused
         M.advect_scalar2D_host(f, inp["u"].astype(np.float64, order="F"), inp["w"], inp["rho"],
                                inp["rhow"], flux, inp["adz"])

@@ -3,12 +3,16 @@ mpdata_kernel_wm_body.h + the layout conversions of mpdata_layout.hip), through 
 plan_create / upload / run / download with HOST arrays in the reference layout, and
 import_device / run_tracers / export_device with DEVICE arrays.
 
-Bars as in test_hip_parity.py: EXACT -> f bit-identical to the oracle and to the reference's
-golden outputs, flux within 1e-13 relative (other summation order); FAST -> max|d| < 1e-12 on
+Bars: EXACT -> f AND flux bit-identical to the oracle and to the reference's golden outputs (round 4: the
+limited vertical fluxes are parked and added in the reference's order); FAST -> max|d| < 1e-12 on
 conditioned inputs, rel-L1 < 1e-14 on reference-raw inputs.
 """
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from util import golden_cases, load_golden, max_abs, to_dev, to_host
 
@@ -16,14 +20,14 @@ pytestmark = pytest.mark.gpu
 
 TOL_ABS = 1e-12
 TOL_RELL1 = 1e-14
-FLUX_RTOL = 1e-13
+FLUX_RTOL = 0.0   # (EXACT plans: bit-identical since round 4)
 
 
 def flux_close(flux, flux_ref):
-    nzm = flux.shape[1] - 1
-    a, b = flux[:, :nzm], flux_ref[:, :nzm]
-    ok = np.all(np.abs(a - b) <= FLUX_RTOL * np.maximum(1.0, np.abs(b)))
-    return bool(ok) and np.array_equal(flux[:, nzm], flux_ref[:, nzm])
+    """EXACT through the plan API (round 4): flux(:, 1:nzm) is BIT-IDENTICAL to the reference -- the kernels park the limited
+    vertical fluxes and a finishing kernel adds them onto the upwind sum one by one in the reference's order (:545, :624) --
+    and flux(:, nz) is untouched."""
+    return bool(np.array_equal(flux, flux_ref))
 
 
 @pytest.fixture(scope="module")
@@ -187,7 +191,7 @@ def test_wavemajor_tracer_batch_and_subranges(M, oracle, variant):
 
 def test_layouts_agree_bitwise(M, oracle):
     """The same plan calls in the reference layout (x-march kernel) and the wave-major layout:
-    EXACT bit-identical (same arithmetic, same order); FAST equal up to the compiler's choice of
+    EXACT f bit-identical (same arithmetic, same order); FAST equal up to the compiler's choice of
     FMA contractions in the two kernels (reference metric, raw inputs)."""
     inp = oracle.make_inputs(200, 32, 28, seed=3, dist=3)
     for var in (M.VARIANT_EXACT, M.VARIANT_FAST):
@@ -207,7 +211,13 @@ def test_layouts_agree_bitwise(M, oracle):
             M.set_plan_layout(M.LAYOUT_WAVEMAJOR)
         if var == M.VARIANT_EXACT:
             assert np.array_equal(f1, f2)
-            assert np.array_equal(fl1, fl2)
+            # flux: the wave-major plan is bit-identical to the reference (parked limited fluxes, round 4); the
+            # x-march kernel of a reference-layout plan adds its two partial sums (1e-13), level nz untouched in both
+            nzm_ = fl1.shape[1] - 1
+            assert np.all(np.abs(fl1[:, :nzm_] - fl2[:, :nzm_]) <= 1e-13 * np.maximum(1.0, np.abs(fl1[:, :nzm_])))
+            assert np.array_equal(fl1[:, nzm_], fl2[:, nzm_])
+            _, flux_ref = oracle.advect(inp, nthreads=4)
+            assert np.array_equal(fl1, flux_ref)
         else:
             assert oracle.rel_l1(f1, f2) < TOL_RELL1
             assert oracle.rel_l1(fl1[:, :-1], fl2[:, :-1]) < TOL_RELL1
@@ -320,3 +330,27 @@ def test_random_shapes_tracer_batches(M, oracle):
             f_ref, flux_ref = oracle.advect(dict(base, f=fs[t].copy()), nthreads=4)
             assert np.array_equal(f[..., t], f_ref), (ncrms, nx, nz, ntr, t, it, max_abs(f[..., t], f_ref))
             assert flux_close(np.asfortranarray(flux[..., t]), flux_ref), (ncrms, nx, nz, ntr, t, it)
+
+
+def test_exact_flux_without_the_park_array(oracle):
+    """MPDATA_EXACT_FLUX=sum (read once per process: a child process): EXACT plans without the park array of the
+    bit-identical flux -- f still bit-identical, flux(:, 1:nzm) = upwind sum + limited sum, equal to 1e-13 relative."""
+    import os, subprocess, sys, json
+    code = (
+        "import json, numpy as np, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import codesign_kernels_amd as M\n"
+        "from oracle import oracle as O\n"
+        "O.build_lib(); M.set_variant(M.VARIANT_EXACT)\n"
+        "inp = O.make_inputs(130, 31, 28, seed=5, dist=3)\n"
+        "p = M.Plan(130, 31, 28, 1); p.upload(inp['f'], inp['u'], inp['w'], inp['rho'], inp['rhow'], inp['adz'], inp['flux']); p.run(); p.sync()\n"
+        "f = np.empty_like(inp['f'], order='F'); fl = np.empty_like(inp['flux'], order='F'); p.download(f, fl); p.close()\n"
+        "fr, flr = O.advect(inp, nthreads=2)\n"
+        "d = np.abs(fl[:, :-1] - flr[:, :-1]); tol = 1e-13 * np.maximum(1.0, np.abs(flr[:, :-1]))\n"
+        "print('RESULT ' + json.dumps({'f': bool(np.array_equal(f, fr)), 'flux_close': bool(np.all(d <= tol)), 'flux_equal': bool(np.array_equal(fl, flr))}))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPDATA_EXACT_FLUX="sum"), capture_output=True,
+                       text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["f"] and res["flux_close"]
