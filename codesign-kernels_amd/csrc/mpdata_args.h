@@ -21,6 +21,8 @@ struct MpdataArgsT {
   long long f_tstride;     // elements between consecutive tracers of f
   long long flux_tstride;  // ... of flux
   unsigned long long* dbg;  // unused by these kernels (the wave-major kernels' diagnostic build has its own: MpdataWmArgsT::dbg)
+  R* wpark;                 // x-marching kernels, EXACT only, may be null: park array of the limited vertical fluxes,
+                            // [workgroup][column 1..nx][thread] (bit-identical flux: xmarch_flux_finish_kernel adds them in order)
 };
 typedef MpdataArgsT<double> MpdataArgs;
 typedef MpdataArgsT<float> MpdataArgsF32;

@@ -259,6 +259,12 @@ void arena_free(Arena& a) {
   a = Arena();
 }
 
+// EXACT plans: flux bit-identical to the reference (the limited vertical fluxes parked and added in the reference's
+// order) unless MPDATA_EXACT_FLUX=sum
+bool exact_flux_in_order() {
+  static const bool sum = getenv("MPDATA_EXACT_FLUX") && !strcmp(getenv("MPDATA_EXACT_FLUX"), "sum");
+  return !sum;
+}
 // var: MPDATA_VARIANT_* (a plan passes the variant it was created with; < 0: the global one)
 template <typename R>
 int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u, const R* w,
@@ -277,6 +283,19 @@ int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u,
   a.f_tstride = (long long)ncrms * (nx + 6) * (nz - 1);
   a.flux_tstride = (long long)ncrms * nz;
   a.dbg = g_dbg;
+  // EXACT, x-marching kernels: the park array of the bit-identical flux (see xmarch_flux_finish_kernel), allocated and
+  // freed in stream order around the launch: [workgroup][nx][thread].  (The k-marching kernels add in the reference's
+  // order by construction; FAST never parks; MPDATA_EXACT_FLUX=sum does without.)
+  a.wpark = nullptr;
+  void* park_mem = nullptr;
+  const bool big = (double)ncrms * (nx + 6) * nz * (double)(t.id >= 40 ? 8 : t.elem_bytes) >= 4294967000.0 * (t.id >= 40 ? 2 : 1);
+  if (var == MPDATA_VARIANT_EXACT && t.nz_max < (1 << 30) && !big && exact_flux_in_order()) {
+    const size_t groups = (size_t)((ncrms + t.slw - 1) / t.slw);
+    const size_t esz = t.id >= 40 ? 8 : (size_t)t.elem_bytes;   // (tile ids 40..: two fp32 instances per lane)
+    const size_t bytes = (size_t)ntracers * groups * (size_t)nx * (size_t)t.threads * esz;
+    HIP_TRY(hipMallocAsync(&park_mem, bytes, (hipStream_t)stream));
+    a.wpark = (R*)park_mem;
+  }
   bool ok;
   if constexpr (sizeof(R) == 8)
     ok = var == MPDATA_VARIANT_FAST ? mpdata_fast::launch(t.id, a, ntracers, stream)
@@ -284,6 +303,7 @@ int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u,
   else
     ok = var == MPDATA_VARIANT_FAST ? mpdata_fast::launch_f32(t.id, a, ntracers, stream)
                                     : mpdata_exact::launch_f32(t.id, a, ntracers, stream);
+  if (park_mem) (void)hipFreeAsync(park_mem, (hipStream_t)stream);
   if (!ok) return set_err(MPDATA_EINVAL, "tile %d not instantiated", t.id);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -405,12 +425,7 @@ int wm_flags() {
   return g_wm_flags;
 }
 int wm_wpb() { return 4; }
-// EXACT plans: flux bit-identical to the reference (the limited vertical fluxes parked and added in the reference's
-// order) unless MPDATA_EXACT_FLUX=sum
-bool exact_flux_in_order() {
-  static const bool sum = getenv("MPDATA_EXACT_FLUX") && !strcmp(getenv("MPDATA_EXACT_FLUX"), "sum");
-  return !sum;
-}  // waves (tiles) per workgroup of the wave-major kernels
+  // waves (tiles) per workgroup of the wave-major kernels
 struct DevGuard {
   int prev = -1, dev;
   explicit DevGuard(int d) : dev(d) {

@@ -294,6 +294,24 @@ struct Window {
   R SF[3];                                     // wave-major two-tracer FAST form only: f1 + f1(kb) of column q-1
 };
 
+// workgroup (dispatch index) -> (tracer, instance group): tracer is the FASTEST index, so the workgroups that share the
+// same rows of u, w, rho, rhow, adz are dispatched together; tracer batches are additionally re-dealt so that all
+// tracers of group g go to XCD g % 8, back to back (workgroups are dealt to the 8 XCDs round-robin in dispatch order:
+// 24 of 25 reads of that group's u, w rows then hit in that XCD's L2)
+__device__ __forceinline__ void xm_block_map(const unsigned L, const unsigned nblocks, const unsigned ntr, int& tr, unsigned& grp) {
+  tr = (int)(L % ntr);
+  grp = L / ntr;
+  if (ntr > 1) {
+    const unsigned nxcd = 8;
+    const unsigned full = ((nblocks / ntr) / nxcd) * nxcd;   // groups the re-deal covers
+    if (L < ntr * full) {
+      const unsigned xcd = L % nxcd, j = L / nxcd;
+      tr = (int)(j % ntr);
+      grp = (j / ntr) * nxcd + xcd;
+    }
+  }
+}
+
 // BIG: some array is 4 GiB or larger.  Then every buffer descriptor starts at the first row
 // (level) its wave touches, so the per-lane 32-bit offsets only span the wave's few rows (the
 // column offset, a 32-bit scalar, needs ncrms * (nx+6) * sizeof(R) < 4 GiB).  Otherwise one
@@ -319,27 +337,9 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler too
-  // grid = (tracers, instance groups): tracer is the FASTEST block index, so the
-  // workgroups that share the same rows of u,w,rho,rhow,adz are dispatched together and
-  // all but the first read them from the L2 / Infinity Cache instead of HBM
-  // grid = ntracers * groups workgroups in one dimension, tracer fastest (a.ntracers)
-  const unsigned ntr_ = (unsigned)a.ntracers;
-  int tr = (int)(blockIdx.x % ntr_);
-  unsigned grp = blockIdx.x / ntr_;
-  // Tracer batches: workgroups are dealt to the 8 XCDs round-robin in dispatch order, so with
-  // the plain mapping the tracers of one instance group land on 8 different L2s.  Re-deal
-  // them: all tracers of group g go to XCD g % 8, back to back, and 24 of 25 reads of that
-  // group's u, w rows hit in that XCD's L2.
-  if (ntr_ > 1) {
-    const unsigned ntr = ntr_, nxcd = 8;
-    const unsigned L = blockIdx.x;                      // dispatch order
-    const unsigned full = ((gridDim.x / ntr) / nxcd) * nxcd;   // groups the re-deal covers
-    if (L < ntr * full) {
-      const unsigned xcd = L % nxcd, j = L / nxcd;
-      tr = (int)(j % ntr);
-      grp = (j / ntr) * nxcd + xcd;
-    }
-  }
+  int tr;
+  unsigned grp;
+  xm_block_map(blockIdx.x, gridDim.x, (unsigned)a.ntracers, tr, grp);
   const long long sl_base = (long long)grp * G;
 
   R* const f = a.f + (long long)tr * a.f_tstride;
@@ -481,6 +481,18 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
     S.MXN[j] = S.MNN[j] = S.U3[j] = S.DW3[j] = R(0);
   }
   R S1 = R(0), S3 = R(0);
+  // EXACT with a park array: the reference adds the limited vertical fluxes ONE BY ONE onto the finished upwind sum
+  // (:545, :624), and the first of them exists 30 columns before that sum is complete -- every lane parks its nx limited
+  // fluxes ([workgroup][column][thread]), flux gets the upwind sum alone, xmarch_flux_finish_kernel adds the rest in order
+  // (not in the instantiation for arrays of 4 GiB and more: its per-wave descriptors leave no scalar registers for it)
+#ifdef MPDATA_FAST_DIV
+  constexpr bool CAN_PARK = false;
+#else
+  constexpr bool CAN_PARK = !BIG;
+#endif
+  [[maybe_unused]] const bool park = CAN_PARK && a.wpark != nullptr;
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsp =
+      make_rsrc(a.wpark + (long long)blockIdx.x * nx * T::THREADS, park ? (long long)nx * T::THREADS * RB : 0);
 
   // One step of the march.  PH = (q+2) mod 3 selects the ring slots at compile
   // time; FULL = steady state (4 <= q <= nx): every stage is active.
@@ -646,7 +658,14 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
         const R mxd = DN_C(MXN_2);
         const R mnd = DN_C(MNN_2);
         const R W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
-        S3 = S3 + W3;  // :624
+        if (CAN_PARK && park) {   // EXACT, bit-identical flux: parked, added behind the launch in the reference's order
+          unsigned z;   // (the lane's byte offset from the execution mask: no register carries it through the march)
+          asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+          const unsigned lo = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)) * (unsigned)RB;
+          st_row<0>(rsp, lo, (unsigned)(((q - 3) * T::THREADS + wave * 64) * RB), W3);
+        } else {
+          S3 = S3 + W3;  // :624
+        }
         DW3_2 = UP_G(W3) - W3;
       }
     }
@@ -761,7 +780,29 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
     }
   }
 
-  if (lvl_ok && slc_ok) flux[sl_c + ncrms * (long long)(k - 1)] = S1 + S3;  // :541-547, :624
+  if (lvl_ok && slc_ok) flux[sl_c + ncrms * (long long)(k - 1)] = (CAN_PARK && park) ? S1 : S1 + S3;  // :541-547, :624
+}
+
+// EXACT, bit-identical flux: flux (the upwind sum, as the kernel above left it) += the nx parked limited vertical
+// fluxes of the lane, one by one in the reference's order i = 1 .. nx (:624).  Same grid, same thread -> (tracer,
+// instance, level) mapping as the kernel above.  (Built without contraction in both variants' translation units?  No:
+// only the EXACT one launches it.)
+template <typename R, int LPS, int G>
+__global__ void __launch_bounds__(G * LPS) xmarch_flux_finish_kernel(const MpdataArgsT<R> a) {
+  using T = TileV2<R, LPS, G>;
+  const int nx = a.nx, nzm = a.nz - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tr;
+  unsigned grp;
+  xm_block_map(blockIdx.x, gridDim.x, (unsigned)a.ntracers, tr, grp);
+  const int kk = lane % LPS;
+  const long long sl_c = (long long)grp * G + wave * T::SLP + lane / LPS;
+  if (kk >= nzm || sl_c >= a.ncrms) return;
+  R* fp = a.flux + (long long)tr * a.flux_tstride + sl_c + a.ncrms * (long long)kk;
+  const R* pp = a.wpark + (long long)blockIdx.x * nx * T::THREADS + tid;
+  R acc = *fp;
+  for (int i = 0; i < nx; ++i) acc = acc + pp[(long long)i * T::THREADS];
+  *fp = acc;
 }
 
 }  // namespace v2

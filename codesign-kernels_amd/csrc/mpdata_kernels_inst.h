@@ -68,6 +68,10 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
     hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, false, true>), grid, block, 0, (hipStream_t)stream, b);
   else
     hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, false>), grid, block, 0, (hipStream_t)stream, b);
+#ifndef MPDATA_FAST_DIV
+  // EXACT with a park array: the limited vertical fluxes onto the upwind sum, in the reference's order (bit-identical flux)
+  if (b.wpark && !big) hipLaunchKernelGGL((v2::xmarch_flux_finish_kernel<R, LPS, G>), grid, block, 0, (hipStream_t)stream, b);
+#endif
 }
 
 // wave-major kernels (mpdata_kernel_wm_body.h, the plan API): LPS = lanes per instance (>= nz),
@@ -290,6 +294,7 @@ bool launch_f32(int id, const MpdataArgsF32& a, int ntracers, void* stream) {
     p.ncrms = a.ncrms / 2; p.nx = a.nx; p.nz = a.nz; p.ntracers = ntracers;
     p.f_tstride = a.f_tstride / 2; p.flux_tstride = a.flux_tstride / 2;
     p.dbg = a.dbg;
+    p.wpark = reinterpret_cast<v2::f32x2*>(a.wpark);
 #define X(ID, LPS_, G_)                                        \
   if (id == ID) {                                              \
     launch_tile_v2<v2::f32x2, LPS_, G_>(p, ntracers, stream);  \

@@ -47,26 +47,23 @@ extern "C" {
 /* kernel variants (mpdata_set_variant / MPDATA_VARIANT env): */
 #define MPDATA_VARIANT_EXACT 0  /* no FMA contraction, IEEE divide, the reference's
                                    expression order: f (every element, halos
-                                   included) is BIT-IDENTICAL to the reference
-                                   CPU routine built with -ffp-contract=off.
-                                   flux(:,1:nzm): BIT-IDENTICAL as well through
-                                   the plan API in its own layout (section 3: the
-                                   kernels park the nx limited vertical fluxes of
-                                   every lane and a finishing kernel adds them
-                                   onto the finished upwind sum one by one, the
-                                   reference's order :545, :624; costs a park
-                                   array of the size of f's interior per tracer,
-                                   allocated with an EXACT plan, and a third of
-                                   the EXACT variant's speed; MPDATA_EXACT_FLUX=sum
-                                   in the environment does without both: flux
-                                   then as below).  Calls on
-                                   reference-layout device arrays (section 2) and
-                                   reference-layout plans: the sum of the
-                                   reference's terms in another order (sum of
-                                   upwind terms + sum of limited terms, each in
-                                   the reference's i order): equal to <= 1e-13
-                                   relative, not bitwise (bit-exact there: the
-                                   k-marching kernels, mpdata_set_tile(0..4)). */
+                                   included) AND flux(:,1:nzm) are BIT-IDENTICAL
+                                   to the reference CPU routine built with
+                                   -ffp-contract=off.  For flux the kernels park
+                                   the nx limited vertical fluxes of every lane
+                                   and a finishing kernel adds them onto the
+                                   finished upwind sum one by one, the
+                                   reference's order :545, :624 (a park array of
+                                   the size of f's interior per tracer: with an
+                                   EXACT plan, or allocated and freed in stream
+                                   order around a device call; a third of the
+                                   EXACT variant's speed).  MPDATA_EXACT_FLUX=sum
+                                   in the environment does without it, and calls
+                                   on arrays of 4 GiB and more never park: flux is
+                                   then the sum of the reference's terms in
+                                   another order (sum of upwind terms + sum of
+                                   limited terms, each in the reference's i
+                                   order), equal to <= 1e-13 relative. */
 #define MPDATA_VARIANT_FAST 1   /* FMA contraction allowed, Newton reciprocal in
                                    the limiter: differs from the above by
                                    rounding only (< 1e-12 abs on conditioned

@@ -21,15 +21,18 @@ pytestmark = pytest.mark.gpu
 
 TOL_ABS = 1e-12     # north_star tolerance, conditioned inputs
 TOL_RELL1 = 1e-14   # reference metric, raw inputs
-FLUX_RTOL = 1e-13   # x-marching kernels: summation order of flux differs
+FLUX_RTOL = 1e-13   # only left for arrays of 4 GiB and more (their x-march instantiation does not park, see flux_close)
 KMARCH_TILES = [0, 1, 2, 3, 4]   # nx <= 32 (ids 3, 4: nx <= 68 / 140), any nz
 XMARCH_TILES = [22, 23, 24]      # nz <= 32 / 64 / 32 (256-byte rows), any nx
 
 
-def flux_close(flux, flux_ref):
+def flux_close(flux, flux_ref, rtol=0.0):
+    """EXACT: flux(:, 1:nzm) BIT-IDENTICAL to the reference since round 4 (the x-marching kernels park the limited
+    vertical fluxes of every lane and a finishing kernel adds them onto the upwind sum in the reference's order, :545,
+    :624); rtol = FLUX_RTOL only for arrays of 4 GiB and more, whose kernel instantiation adds the two partial sums."""
     nzm = flux.shape[1] - 1
     a, b = flux[:, :nzm], flux_ref[:, :nzm]
-    ok = np.all(np.abs(a - b) <= FLUX_RTOL * np.maximum(1.0, np.abs(b)))
+    ok = np.array_equal(a, b) if rtol == 0.0 else np.all(np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b)))
     return bool(ok) and np.array_equal(flux[:, nzm], flux_ref[:, nzm])
 
 
@@ -270,7 +273,7 @@ def test_arrays_larger_than_4GiB(M, oracle, variant):
         f = to_host(d["f"][..., s0:s0 + n])
         flux = to_host(d["flux"][..., s0:s0 + n])
         if variant == M.VARIANT_EXACT:
-            assert np.array_equal(f, f_ref) and flux_close(flux, flux_ref)
+            assert np.array_equal(f, f_ref) and flux_close(flux, flux_ref, FLUX_RTOL)
         else:
             assert max_abs(f, f_ref) < TOL_ABS and max_abs(flux, flux_ref) < TOL_ABS
     # the fast kernel, not the fallback: 9.2x the cells of config 3 in well under 9.2 x 1.5 ms
