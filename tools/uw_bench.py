@@ -21,6 +21,7 @@ ap.add_argument("--no-plan", action="store_true")
 ap.add_argument("--no-uw", action="store_true")
 ap.add_argument("--no-conv", action="store_true")
 ap.add_argument("--batch", type=int, default=0, help="also: run_uw on plans of this many tracers (fresh u, w per step)")
+ap.add_argument("--batch-steps", type=int, default=12, help="timed steps of the tracer-batch loops")
 a = ap.parse_args()
 M.set_variant(M.VARIANT_FAST if a.variant == "fast" else M.VARIANT_EXACT)
 dev = torch.device("cuda", 0)
@@ -92,9 +93,9 @@ if a.batch > 1:   # tracer batches on fresh reference-layout u, w: MPDATA_RUN_UW
     torch.cuda.synchronize()
     abT = M.algorithmic_bytes(ncrms, nx, nz, T)
     # (run() first: run_uw leaves no velocities in a plan)
-    ms = timed(lambda i: plans[i % nb].run(), 12, 4)
+    ms = timed(lambda i: plans[i % nb].run(), a.batch_steps, 4)
     print(f"plan   T={T} cold : {ms:.4f} ms  {cells * T / ms / 1e6:.1f} Gcu/s  frac {abT / ms / 1e6 / 8000:.4f}")
-    ms = timed(lambda i: plans[i % nb].run_uw(sets[(i + 1) % n][1], sets[(i + 1) % n][2]), 12, 4)
+    ms = timed(lambda i: plans[i % nb].run_uw(sets[(i + 1) % n][1], sets[(i + 1) % n][2]), min(a.batch_steps, 12), 4)
     print(f"run_uw T={T} cold : {ms:.4f} ms  {cells * T / ms / 1e6:.1f} Gcu/s  frac {abT / ms / 1e6 / 8000:.4f}  ({os.environ.get('MPDATA_RUN_UW', 'direct')})")
     for p in plans:
         p.close()
