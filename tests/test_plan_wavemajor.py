@@ -154,6 +154,28 @@ def test_tracer_batches_two_tracers_per_wave(M, oracle, monkeypatch, shape, ntr,
         assert_parity(M, oracle, var, 3, f[..., t], flux[..., t], f_ref, flux_ref)
 
 
+@pytest.mark.parametrize("shape", [(64, 32, 28), (37, 32, 17), (21, 33, 33), (10, 6, 64), (130, 31, 12), (7, 2, 4), (258, 5, 28)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("ntr", [8, 9, 16])
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_tracer_batches_whose_workgroups_hold_one_tile(M, oracle, shape, ntr, mode):
+    """Tracer pairs per tile a multiple of four (8, 9 = 8 + the odd one, 16 tracers): the four waves of a workgroup are
+    then four pairs of the SAME tile (the XCD walk of the batch launch).  Every tracer against the oracle on all lane
+    mappings and ragged tile counts."""
+    var = M.VARIANT_FAST if mode == "fast" else M.VARIANT_EXACT
+    M.set_variant(var)
+    ncrms, nx, nz = shape
+    base = oracle.make_inputs(ncrms, nx, nz, seed=21, dist=3)
+    fs = [oracle.make_inputs(ncrms, nx, nz, seed=310 + t, dist=3)["f"] for t in range(ntr)]
+    inp = dict(base)
+    inp["f"] = np.asfortranarray(np.stack(fs, axis=-1))
+    inp["flux"] = np.asfortranarray(np.stack([base["flux"]] * ntr, axis=-1))
+    f, flux = run_plan_host(M, inp, ntr=ntr)
+    for t in range(ntr):
+        f_ref, flux_ref = oracle.advect(dict(base, f=fs[t].copy()), nthreads=4)
+        assert_parity(M, oracle, var, 3, f[..., t], flux[..., t], f_ref, flux_ref)
+
+
 @pytest.mark.parametrize("variant", ["exact", "fast"])
 def test_wavemajor_tracer_batch_and_subranges(M, oracle, variant):
     """T tracers sharing u, w, rho, rhow, adz == T single-tracer calls of the oracle; a sub-range
