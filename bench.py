@@ -45,6 +45,9 @@ def parse():
                     help="untimed GPU wake-up before the warm-up steps: scratch launches of the same kernel for "
                          "about this long, so that the clock / power-state ramp after idle (DESIGN.md 4.4) is "
                          "over even when --warmup is small; 0 disables")
+    ap.add_argument("--block-timeout", type=float, default=float(os.environ.get("MPDATA_BENCH_BLOCK_TIMEOUT", "420")),
+                    help="seconds a side block (set-up, timing and the ranks' agreement after it) may take before the "
+                         "watchdog ends the run with the line printed (class Lifeline); 0 disables")
     ap.add_argument("--ncrms-per-gpu", type=int, default=65536)
     ap.add_argument("--nx", type=int, default=32)
     ap.add_argument("--nz", type=int, default=28)
@@ -353,9 +356,83 @@ CURRENT_BLOCK = [None]   # name of the side block that is running (failure injec
 def inject_failure(name, phase):
     for spec in FAIL_SPEC.split(","):
         parts = spec.split(":")
-        if len(parts) >= 2 and parts[0] == name and int(parts[1]) == int(os.environ.get("RANK", "0")) and \
-                (parts[2] if len(parts) > 2 else "start") == phase:
+        if len(parts) < 2 or parts[0] != name or int(parts[1]) != int(os.environ.get("RANK", "0")):
+            continue
+        how = parts[2] if len(parts) > 2 else "start"
+        if how == "hang" and phase == "start":     # a rank that never comes back (a hung collective, a stuck kernel)
+            while True:
+                time.sleep(1.0)
+        if how == "kill" and phase == "start":     # a rank that dies without a word (SIGKILL: out of memory, a GPU fault)
+            os.kill(os.getpid(), 9)
+        if how == phase:
             raise InjectedFailure(f"injected failure in block {name!r} ({phase}) on rank {parts[1]}")
+
+
+class Lifeline:
+    """What no try / except can catch.  (a) A block that never ends -- a collective that hangs because a rank is
+    gone, a kernel that does not finish: a thread on every rank watches the deadline of the running block; when it
+    passes, rank 0 records an error entry under the block's name, prints THE line with everything measured so far
+    and every rank leaves with exit code 0.  (b) SIGTERM -- what torch.distributed.run sends to the surviving ranks
+    when one rank died: SIGTERM is blocked in every thread (the mask is set before torch is imported and creates its
+    threads) and taken by a thread of its own with sigwait, so it is served even while the main thread sits in a
+    collective; rank 0 prints the line, then the process exits with 143.  The line goes out once, whoever prints it."""
+
+    def __init__(self):
+        import signal
+        import threading
+        self.lock = threading.Lock()
+        self.printed = False
+        self.result = None          # rank 0: the dict of the line, once the headline exists
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.block, self.deadline, self.seconds = None, None, 0.0
+        signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+        threading.Thread(target=self._sigterm, daemon=True).start()
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def print_line(self, extra=None):
+        with self.lock:
+            if self.printed or self.rank != 0 or self.result is None:
+                return
+            self.printed = True
+            for _ in range(3):      # (the main thread may be writing into the dict)
+                try:
+                    line = json.dumps(dict(self.result, **(extra or {})))
+                    break
+                except RuntimeError:
+                    time.sleep(0.05)
+            else:
+                line = json.dumps(extra or {})
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
+
+    def arm(self, block, seconds):
+        self.block, self.seconds = block, seconds
+        self.deadline = time.monotonic() + seconds if seconds > 0 else None
+
+    def disarm(self):
+        self.deadline, self.block = None, None
+
+    def _sigterm(self):
+        import signal
+        signal.sigwait({signal.SIGTERM})
+        blk = self.block
+        self.print_line({"terminated": "SIGTERM" + (f" during block {blk!r}" if blk else "") +
+                         " (another rank died?): the line holds what was measured until then"})
+        os._exit(143)
+
+    def _watch(self):
+        while True:
+            time.sleep(0.5)
+            dl, blk = self.deadline, self.block
+            if dl is None or time.monotonic() < dl:
+                continue
+            msg = f"watchdog: block {blk!r} had not ended after {self.seconds:.0f} s (a hang or a lost rank); the run was ended here"
+            if self.rank == 0:
+                print("BENCH_WATCHDOG " + msg, file=sys.stderr, flush=True)
+                self.print_line({blk: {"error": msg}} if blk else {"watchdog": msg})
+            else:
+                time.sleep(2.0)     # (rank 0 first)
+            os._exit(0)
 
 
 def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=None, collective=True):
@@ -633,6 +710,7 @@ def main():
     args = parse()
     ALIGNED = args.aligned
     PREWARM_MS = args.prewarm_ms
+    life = Lifeline()     # (before torch: its threads inherit the blocked SIGTERM)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -774,6 +852,7 @@ def main():
         # the headline exists: on stderr at once (a later block that takes the process down cannot lose it);
         # stdout gets the ONE full line at the end
         print("BENCH_HEADLINE " + json.dumps(result), file=sys.stderr, flush=True)
+        life.result = result
 
     # ---- side blocks.  Each one is a closure that does its set-up AND its timing WITHOUT any collective and
     #      returns (seconds of its K steps on this rank, entry(max seconds over the ranks) -> dict).  An
@@ -784,6 +863,7 @@ def main():
             return
         failed, dt_loc, entry, msg = False, 0.0, None, None
         CURRENT_BLOCK[0] = name
+        life.arm(name, args.block_timeout)
         try:
             if not rank0_only or rank == 0:
                 inject_failure(name, "start")
@@ -796,7 +876,12 @@ def main():
             torch.cuda.empty_cache()
         except Exception as exc:
             failed, msg = True, msg or repr(exc)
-        any_failed, dt_max = (failed, dt_loc) if rank0_only else agree(failed, dt_loc)
+        try:
+            any_failed, dt_max = (failed, dt_loc) if rank0_only else agree(failed, dt_loc)
+        except Exception as exc:   # the process group is gone (a rank died): nothing more can be measured
+            life.print_line({name: {"error": "the ranks' agreement after the block failed (a rank died?): " + repr(exc)}})
+            os._exit(1)
+        life.disarm()
         if rank == 0:
             if any_failed:
                 result[name] = {"error": msg or "the block failed on another rank"}
@@ -1034,11 +1119,12 @@ def main():
                 result["cpu_baseline"] = {"error": repr(exc)}
     finally:
         # whatever happened above (an exception outside a block's own handler, Ctrl-C): the line goes out
-        if rank == 0:
-            print(json.dumps(result), flush=True)
+        life.print_line()
     if world > 1:
+        life.arm(None, 60.0 if args.block_timeout > 0 else 0.0)   # (the line is out: a rank that hangs here only costs the exit)
         dist.barrier()
         dist.destroy_process_group()
+        life.disarm()
 
 
 def bench_scatter_gather(M, torch, dist, world, rank, dev, n_loc, nx, nz):

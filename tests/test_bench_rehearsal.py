@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _two_ranks(extra_env=None, extra_args=()):
+def _two_ranks(extra_env=None, extra_args=(), rc0=True):
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a port the OS hands out
         sk.bind(("127.0.0.1", 0))
@@ -23,7 +23,7 @@ def _two_ranks(extra_env=None, extra_args=()):
            "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--ncrms-per-gpu", "4096",
            "--batched-tracers", "3", "--batched-steps", "2", "--no-fp32", "--no-bwk", "--no-cpu-baseline", *extra_args]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert (res.returncode == 0) == rc0, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout                     # rank 0 only
     return json.loads(lines[0]), res
@@ -65,3 +65,29 @@ def test_headline_only():
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
     for k in ("tracer_batched", "twice_the_instances", "reference_layout_device_call", "fp32", "scatter_gather"):
         assert k not in d
+
+
+@pytest.mark.gpu
+def test_a_rank_that_hangs_in_a_side_block_cannot_lose_the_line():
+    """Rank 1 never comes back from a side block (what a hung collective or a stuck kernel looks like from outside):
+    rank 0 finishes the block and waits in the ranks' agreement.  The watchdog (bench.py class Lifeline) ends the run
+    at the block's deadline: the line is printed with the headline and every block measured before, an error entry
+    under the block's name, exit code 0 on every rank."""
+    d, res = _two_ranks({"MPDATA_BENCH_FAIL": "reference_layout_device_call:1:hang"}, ("--block-timeout", "25"))
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["tracer_batched"]["value"] > 0 and d["step_with_fresh_uw"]["value"] > 0
+    assert "watchdog" in d["reference_layout_device_call"]["error"]
+    assert "BENCH_WATCHDOG" in res.stderr
+
+
+@pytest.mark.gpu
+def test_a_rank_that_dies_cannot_lose_the_line():
+    """Rank 1 is killed outright inside a side block (SIGKILL, as the out-of-memory killer or a GPU fault would):
+    torch.distributed.run then sends SIGTERM to rank 0, which may sit in a collective at that moment.  The run fails
+    (exit code != 0) but rank 0 still prints the line with everything measured until then."""
+    d, res = _two_ranks({"MPDATA_BENCH_FAIL": "tracer_batched:1:kill"}, rc0=False)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0 and d["steps"] == 3
+    assert d["step_with_fresh_uw"]["value"] > 0 and d["twice_the_instances"]["value"] > 0
+    # (gloo notices the lost peer by itself and the agreement raises; RCCL would wait until the SIGTERM arrives)
+    assert "SIGTERM" in d.get("terminated", "") or "agreement" in d["tracer_batched"]["error"]
+    assert "value" not in d.get("tracer_batched", {})
