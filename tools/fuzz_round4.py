@@ -19,7 +19,7 @@ from util import to_dev, to_host
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 O.build_lib()
-rng = np.random.default_rng(4242)
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "4242")))   # (shapes; FUZZ_SEED draws another sweep)
 bad = 0
 
 
