@@ -373,9 +373,10 @@ class Lifeline:
     gone, a kernel that does not finish: a thread on every rank watches the deadline of the running block; when it
     passes, rank 0 records an error entry under the block's name, prints THE line with everything measured so far
     and every rank leaves with exit code 0.  (b) SIGTERM -- what torch.distributed.run sends to the surviving ranks
-    when one rank died: SIGTERM is blocked in every thread (the mask is set before torch is imported and creates its
-    threads) and taken by a thread of its own with sigwait, so it is served even while the main thread sits in a
-    collective; rank 0 prints the line, then the process exits with 143.  The line goes out once, whoever prints it."""
+    when one rank died, and what a `timeout` sends: the main thread may sit in a collective then and never reach a
+    Python-level handler, so the signal is taken off CPython's wake-up descriptor (the C-level handler writes the
+    signal number there whatever the main thread is doing) by a thread of its own; rank 0 prints the line, then the
+    process exits with 143.  The line goes out once, whoever prints it."""
 
     def __init__(self):
         import signal
@@ -385,7 +386,11 @@ class Lifeline:
         self.result = None          # rank 0: the dict of the line, once the headline exists
         self.rank = int(os.environ.get("RANK", "0"))
         self.block, self.deadline, self.seconds = None, None, 0.0
-        signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+        self.rfd, wfd = os.pipe()
+        os.set_blocking(wfd, False)
+        signal.signal(signal.SIGTERM, lambda signum, frame: None)   # (a Python-level handler arms the C-level one)
+        signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+        self.sigterm = int(signal.SIGTERM)
         threading.Thread(target=self._sigterm, daemon=True).start()
         threading.Thread(target=self._watch, daemon=True).start()
 
@@ -413,8 +418,10 @@ class Lifeline:
         self.deadline, self.block = None, None
 
     def _sigterm(self):
-        import signal
-        signal.sigwait({signal.SIGTERM})
+        while True:
+            b = os.read(self.rfd, 1)
+            if b and b[0] == self.sigterm:
+                break
         blk = self.block
         self.print_line({"terminated": "SIGTERM" + (f" during block {blk!r}" if blk else "") +
                          " (another rank died?): the line holds what was measured until then"})
@@ -710,7 +717,7 @@ def main():
     args = parse()
     ALIGNED = args.aligned
     PREWARM_MS = args.prewarm_ms
-    life = Lifeline()     # (before torch: its threads inherit the blocked SIGTERM)
+    life = Lifeline()
     import numpy as np
     import torch
     import torch.distributed as dist
