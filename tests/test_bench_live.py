@@ -1,0 +1,34 @@
+"""bench.py run live on the GPU (one process, a small shard so that it takes seconds) and its ONE line held against
+the measurement contract (tests/bench_contract.py) -- the same checks the recorded line of the round passes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import bench_contract as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_live_line_meets_the_contract():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+           "--prewarm-ms", "5", "--ncrms-per-gpu", "8192", "--batched-tracers", "3", "--batched-steps", "2",
+           "--no-fp32", "--no-bwk", "--no-host-call"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    C.check_headline(d, 8192)
+    C.check_roofline(d, 8192)
+    C.check_cpu_baseline(d)
+    C.check_no_block_failed(d)
+    assert d["steps"] == 4 and d["warmup"] == 2
+    # the headline on stderr is the headline of the line
+    early = [ln for ln in res.stderr.splitlines() if ln.startswith("BENCH_HEADLINE {")]
+    assert len(early) == 1 and json.loads(early[0].split(" ", 1)[1])["value"] == d["value"]
+    for blk in ("step_with_fresh_uw", "twice_the_instances", "tracer_batched", "reference_layout_device_call"):
+        assert d[blk]["value"] > 0 and 0 < d[blk]["roofline"]["frac"] < 1, blk
