@@ -44,11 +44,13 @@
 // kernel's data movement) -- and over BIG (arrays of 4 GiB or more: per-wave
 // descriptor bases).  DESIGN.md sections 4.1, 4.4, 4.5 have the measurements.
 //
-// f is bit-identical to the reference in the EXACT build.  flux(k) is
-// accumulated per lane as (sum_i upwind) + (sum_i limited), each sum in the
-// reference's i order; the reference adds the limited terms one by one onto
-// the finished upwind sum (:545,:624), so flux differs from it by rounding
-// of the last few ulps (tests bound it at 1e-13 relative).
+// f is bit-identical to the reference in the EXACT build.  flux(k): the
+// reference adds the limited terms one by one onto the finished upwind sum
+// (:545,:624).  EXACT parks the nx limited fluxes of every lane and a finishing
+// kernel adds them in that order (bit-identical; xmarch_flux_finish_kernel);
+// FAST -- and EXACT on arrays of 4 GiB and more, or with MPDATA_EXACT_FLUX=sum --
+// accumulates (sum_i upwind) + (sum_i limited), each sum in the reference's i
+// order: equal to 1e-13 relative.
 //
 // Built with -fno-honor-nans: fmax/fmin then need no operand canonicalisation
 // (v_max_f64 x,x).  No value-changing transformation is enabled by it; inputs
