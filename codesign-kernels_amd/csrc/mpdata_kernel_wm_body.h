@@ -40,8 +40,9 @@
 // u, w use the column index of f (c = i+2): u has no column c = 0, w none at c = 0 and
 // c = nx+5; those chunks exist in memory but are never fetched.
 //
-// f is bit-identical to the reference in the EXACT build; flux as in the x-march kernel
-// (sum of upwind terms + sum of limited terms, each in the reference's i order).
+// f is bit-identical to the reference in the EXACT build; flux as in the x-march kernel: EXACT
+// parks the limited fluxes ([tracer][tile][column][lane], flux_finish_kernel adds them in the
+// reference's order: bit-identical), FAST accumulates sum of upwind terms + sum of limited terms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
