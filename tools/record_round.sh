@@ -4,6 +4,7 @@
 #   gpurun_out/<tag>_final/bench_default.json  bench.py with its defaults (100 + 100 launches)
 #   gpurun_out/<tag>_final/fortran_driver.txt  the Fortran driver: host mode (1 tracer), device mode (25 tracers),
 #                                              ngpus = 1 through the multi-GPU path, 2 shards on one device
+#   gpurun_out/<tag>_final/fortran_side_drivers.txt  bwk_driver and nested_hip (second / third kernel)
 #   gpurun_out/prof_<tag>/                      tools/profile_round.sh (rocprofv3 kernel trace + PMC passes)
 # then here: python tools/pmc_summary.py <tag>; copy the records into profiles/.
 TAG=${1:-r04}
@@ -28,5 +29,15 @@ F=codesign-kernels_amd/fortran/advect
   $F $OUT/case.nml
 } > $OUT/fortran_driver.txt 2>&1
 echo "fortran rc=$?"
+# the drivers of the second and third kernel (the reference's programs of atmosphere/ and nested_loops/)
+D=codesign-kernels_amd/fortran
+{
+  echo "== $D/bwk_driver 16 0   (the reference's shipped size, EXACT)"; $D/bwk_driver 16 0
+  echo "== $D/bwk_driver 5400 1 (a cubed-sphere ne=30 mesh, FAST; host arrays: transfers included)"; $D/bwk_driver 5400 1
+  echo "== $D/nested_hip - 1    (the reference's shipped namelist, FAST)"; $D/nested_hip - 1
+  printf "&nested_nml\n nIters = 20\n nEdges = 819200\n nCells = 89600\n nVertLevels = 100\n nAdv = 10\n/\n" > $OUT/nested32.nml
+  echo "== $D/nested_hip nested32.nml 1   (a mesh 32 x the namelist's, random connectivity, FAST)"; $D/nested_hip $OUT/nested32.nml 1
+} > $OUT/fortran_side_drivers.txt 2>&1
+echo "side drivers rc=$?"
 # the profile passes take ~10 minutes: a gpurun call of their own (PROFILE=0 skips them here)
 if [ "${PROFILE:-1}" = 1 ]; then timeout -k 10 1000 bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1; echo "profile rc=$?"; fi
