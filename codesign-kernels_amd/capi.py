@@ -369,6 +369,11 @@ def advect_scalar2D_host(f, u, w, rho, rhow, flux, adz):
     _check(fn(ncrms, nx, nz, nt, *ptrs))
 
 
+def release_host_buffers():
+    """Free the streams and chunk buffers the host-array call keeps for the calling thread's next call."""
+    _check(lib().mpdata_release_host_buffers())
+
+
 class Plan:
     """Library-owned device state + stream (reference: `!$acc enter data`,
     `update device`, `wait`, `update host`; :105-110, :237-242).  Arrays cross

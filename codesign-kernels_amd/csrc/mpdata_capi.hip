@@ -12,6 +12,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -257,6 +258,27 @@ hipError_t arena_alloc(Arena& a, const size_t bytes[7]) {
 void arena_free(Arena& a) {
   if (a.base) (void)hipFree(a.base);
   a = Arena();
+}
+// the same placement inside an allocation that is kept between calls (cap = its size; grown when needed)
+hipError_t arena_place(Arena& a, size_t& cap, const size_t bytes[7]) {
+  static const size_t residue[7] = {0, 256, 512, 768, 0, 0, 0};
+  size_t off = 0, offs[7];
+  for (int i = 0; i < 7; ++i) {
+    off = (off + 1023) / 1024 * 1024 + residue[i];
+    offs[i] = off;
+    off += bytes[i];
+  }
+  if (!a.base || off + 1024 > cap) {
+    if (a.base) (void)hipFree(a.base);
+    a = Arena();
+    cap = 0;
+    const hipError_t e = hipMalloc(&a.base, off + 1024);
+    if (e != hipSuccess) { a.base = nullptr; return e; }
+    cap = off + 1024;
+  }
+  const uintptr_t b0 = ((uintptr_t)a.base + 1023) / 1024 * 1024;
+  for (int i = 0; i < 7; ++i) a.p[i] = (void*)(b0 + offs[i]);
+  return hipSuccess;
 }
 
 // EXACT plans: flux bit-identical to the reference (the limited vertical fluxes parked and added in the reference's
@@ -1167,7 +1189,46 @@ struct OutJob {
   int set;
   int64_t c0, cw;
 };
+// What a host-array call needs besides the caller's arrays -- two streams, up to three sets of chunk buffers, an event
+// per set -- is kept per HOST THREAD between calls: creating and destroying them costs 6.7 ms per call with this
+// runtime (two hipStreamCreate 4.9 ms, two hipStreamDestroy 1.8 ms; MPDATA_HOST_TRACE=1 prints the phases), which is
+// a sixth of the call at ncrms = 65536 and 95 % of it at the reference's shipped size (48 instances).
+// mpdata_release_host_buffers() frees the calling thread's set; MPDATA_HOST_CACHE=0 keeps nothing (round 1-3's behaviour).
+struct HostCtx {
+  int dev = -1;
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  ChunkBufs set[3];
+  size_t cap[3] = {0, 0, 0};
+  void release() {
+    for (hipStream_t* st : {&s_in, &s_out})
+      if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
+    for (int i = 0; i < 3; ++i) { free_chunk(set[i]); cap[i] = 0; }
+    dev = -1;
+  }
+  ~HostCtx() {   // (a thread that ends gives its buffers back; the process' last thread: before the runtime shuts down)
+    if (dev < 0) return;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return;
+    if (hipSetDevice(dev) == hipSuccess) { release(); (void)hipSetDevice(cur); }
+  }
+};
+thread_local HostCtx t_host;
+bool host_cache_on() {
+  static const bool off = getenv("MPDATA_HOST_CACHE") && !strcmp(getenv("MPDATA_HOST_CACHE"), "0");
+  return !off;
+}
 }  // namespace
+
+int mpdata_release_host_buffers(void) {
+  if (t_host.dev < 0) return 0;
+  int cur = 0;
+  hipError_t e = hipGetDevice(&cur);
+  if (e == hipSuccess) e = hipSetDevice(t_host.dev);
+  if (e != hipSuccess) return hip_err(e, "mpdata_release_host_buffers");
+  t_host.release();
+  (void)hipSetDevice(cur);
+  return 0;
+}
 
 int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* f, const double* u,
                            const double* w, const double* rho, const double* rhow,
@@ -1175,6 +1236,13 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
   int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
   if (!f || !u || !w || !rho || !rhow || !adz || !flux) return set_err(MPDATA_EINVAL, "null array pointer");
+  // MPDATA_HOST_TRACE=1: microseconds since the call began at every phase boundary, on stderr
+  static const bool trace = getenv("MPDATA_HOST_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (trace) fprintf(stderr, "[mpdata host call] %9.1f us  %s\n",
+                       std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(), what);
+  };
   const int64_t C = host_chunk(ncrms);
   const int64_t nchunks = (ncrms + C - 1) / C;
   const int nsets = nchunks >= 3 ? 3 : (int)nchunks;
@@ -1184,29 +1252,40 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
   const size_t hp = (size_t)ncrms * 8;  // host pitch: one row of all instances
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
-  ChunkBufs set[3];
-  hipStream_t s_in = nullptr, s_out = nullptr;
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking);
+  HostCtx once;                                         // (MPDATA_HOST_CACHE=0: released when the call returns)
+  HostCtx& cx = host_cache_on() ? t_host : once;
+  if (e == hipSuccess && cx.dev != dev) {               // the thread moved to another device: start afresh there
+    if (cx.dev >= 0 && hipSetDevice(cx.dev) == hipSuccess) { cx.release(); (void)hipSetDevice(dev); }
+    cx.dev = dev;
+  }
+  ChunkBufs* const set = cx.set;
+  if (e == hipSuccess && !cx.s_in) e = hipStreamCreateWithFlags(&cx.s_in, hipStreamNonBlocking);
+  if (e == hipSuccess && !cx.s_out) e = hipStreamCreateWithFlags(&cx.s_out, hipStreamNonBlocking);
+  const hipStream_t s_in = cx.s_in, s_out = cx.s_out;
   for (int i = 0; i < nsets && e == hipSuccess; ++i) {
     ChunkBufs& b = set[i];
     const size_t nb[7] = {rows_f * C * 8, rows_u * C * 8, rows_w * C * 8, rows_k * C * 8, rows_kz * C * 8,
                           rows_k * C * 8, rows_x * C * 8};
-    e = arena_alloc(b.arena, nb);
+    b.busy = false;
+    e = arena_place(b.arena, cx.cap[i], nb);
     if (e == hipSuccess) {
       b.f = (double*)b.arena.p[0]; b.u = (double*)b.arena.p[1]; b.w = (double*)b.arena.p[2];
       b.rho = (double*)b.arena.p[3]; b.rhow = (double*)b.arena.p[4]; b.adz = (double*)b.arena.p[5];
       b.flux = (double*)b.arena.p[6];
     }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b.run, hipEventDisableTiming);
+    if (e == hipSuccess && !b.run) e = hipEventCreateWithFlags(&b.run, hipEventDisableTiming);
   }
+  mark("streams, buffers, events");
   // ---- the device -> host thread: takes finished chunks in order
   std::mutex mu;
   std::condition_variable cv;
   std::deque<OutJob> q;
   bool done = false;
   hipError_t e_out = hipSuccess;
-  std::thread out_thread([&]() {
+  // (one chunk -- small problems: nothing to overlap, everything goes through s_in on this thread)
+  const bool piped = nchunks > 1;
+  std::thread out_thread;
+  if (piped) out_thread = std::thread([&]() {
     (void)hipSetDevice(dev);
     for (;;) {
       OutJob j;
@@ -1252,8 +1331,15 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
     h2d(b.adz, adz, rows_k);
     h2d(b.flux, flux, rows_x);  // level nz is never written (reference :541,:624): carry it through
     if (e != hipSuccess) break;
+    if (c == 0) mark("first chunk: host -> device queued");
     rc = mpdata_advect_scalar2d_device(cw, nx, nz, ntracers, b.f, b.u, b.w, b.rho, b.rhow, b.adz, b.flux, (void*)s_in);
     if (rc) break;
+    if (c == 0) mark("first chunk: kernel queued");
+    if (!piped) {
+      e = hipMemcpy2DAsync(f + c0, hp, b.f, dp, dp, rows_f, hipMemcpyDeviceToHost, s_in);
+      if (e == hipSuccess) e = hipMemcpy2DAsync(flux + c0, hp, b.flux, dp, dp, rows_x, hipMemcpyDeviceToHost, s_in);
+      break;   // (the stream is drained below)
+    }
     e = hipEventRecord(b.run, s_in);
     if (e != hipSuccess) break;
     {
@@ -1268,17 +1354,19 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
     done = true;
   }
   cv.notify_all();
-  out_thread.join();
+  if (piped) out_thread.join();
+  mark("all chunks back on the host");
   if (e == hipSuccess) e = e_out;
   for (hipStream_t st : {s_in, s_out})
     if (st) {
       const hipError_t e2 = hipStreamSynchronize(st);
       if (e == hipSuccess) e = e2;
-      (void)hipStreamDestroy(st);
     }
-  for (int i = 0; i < 3; ++i) free_chunk(set[i]);
+  mark("streams drained");
+  if (rc || e != hipSuccess) cx.release();              // after an error nothing is kept
   if (rc) return rc;
   if (e != hipSuccess) return hip_err(e, "mpdata_advect_scalar2d (streamed host call)");
+  mark("done");
   return 0;
 }
 

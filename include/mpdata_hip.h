@@ -79,6 +79,11 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers,
                            double* f, const double* u, const double* w,
                            const double* rho, const double* rhow,
                            const double* adz, double* flux);
+/* The call keeps what it needs besides the caller's arrays -- two streams and up to three sets of chunk
+ * buffers (3/8 of the arrays' size at the default chunking) -- for the next call of the same HOST
+ * THREAD (creating and destroying them costs 6.7 ms per call).  This releases the calling thread's
+ * set; a thread that ends releases its own; MPDATA_HOST_CACHE=0 in the environment keeps nothing. */
+int mpdata_release_host_buffers(void);
 
 /* ---- 2. Device-resident call: device pointers, asynchronous on `stream`
  * (a hipStream_t passed as void*; NULL = the default stream).  This is the
