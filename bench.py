@@ -2,7 +2,10 @@
 """bench.py -- MPDATA tracer-advection throughput on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU)
+    (N > 1: one rank per GPU.  Either torch.distributed.run starts the ranks -- WORLD_SIZE is then
+     set -- or the plain command does it itself: before torch is imported and before anything has
+     touched a GPU it starts `python -m torch.distributed.run ... bench.py <same arguments>` as a
+     CHILD process, passes its output through and returns its exit code, see self_launch())
 
 One "step" = one call of advect_scalar2D (the fused HIP kernel) over one batch
 of synthetic input that is already resident in HBM: BASELINE.json configs[2]
@@ -41,10 +44,14 @@ def parse():
     # leave that transient outside the timed region
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--prewarm-ms", type=float, default=60.0,
-                    help="untimed GPU wake-up before the warm-up steps: scratch launches of the same kernel for "
-                         "about this long, so that the clock / power-state ramp after idle (DESIGN.md 4.4) is "
-                         "over even when --warmup is small; 0 disables")
+    ap.add_argument("--prewarm-ms", type=float, default=500.0,
+                    help="CAP of the untimed GPU wake-up before the warm-up steps: scratch launches of the same kernel "
+                         "on cold field sets until their time has settled (plateau rule, wake_up()) or this long, so "
+                         "that the clock / power-state ramp after idle (DESIGN.md 5) is over even when --warmup is "
+                         "small; 0 disables")
+    ap.add_argument("--prewarm-min-ms", type=float, default=40.0,
+                    help="the wake-up lasts at least this long (the first launches after idle run fast, the power "
+                         "management then takes the clock down: three equal groups inside that phase are no plateau)")
     ap.add_argument("--block-timeout", type=float, default=float(os.environ.get("MPDATA_BENCH_BLOCK_TIMEOUT", "420")),
                     help="seconds a side block (set-up, timing and the ranks' agreement after it) may take before the "
                          "watchdog ends the run with the line printed (class Lifeline); 0 disables")
@@ -311,7 +318,8 @@ def make_shared(M, torch, dev, ncrms_loc, ncrms_glob, sl0, nx, nz, dist, dtype):
 
 ALIGNED = False  # --aligned (reference-layout side measurement only)
 N_SCRATCH = 3    # field buffers the warm-up launches cycle through (their results are not used)
-PREWARM_MS = 60.0  # --prewarm-ms
+PREWARM_MS = 500.0     # --prewarm-ms (cap of the plateau rule)
+PREWARM_MIN_MS = 40.0  # --prewarm-min-ms
 # VALU instructions one wave executes per call at nx=32, nz=28 (rocprofv3 SQ_INSTS_VALU / SQ_WAVES,
 # profiles/r02_pmc_summary.json) and the measured fp64 VALU issue peak of the chip
 # (tools/valu_rate.hip: 33e12 lane-ops/s = 515.6e9 wave-instructions/s)
@@ -442,6 +450,41 @@ class Lifeline:
             os._exit(0)
 
 
+def wake_up(torch, prewarm_launch, cap_ms, min_ms):
+    """GPU wake-up before the warm-up steps, PLATEAU rule: scratch launches of the block's own kernel on cold field
+    sets, in groups of 8 with one HIP-event pair per group, until three consecutive groups agree within 1 % (and at
+    least `min_ms` have passed: the first launches after idle run FAST, then the power management takes the clock
+    down) or `cap_ms` have passed.  A fixed 60 ms (round 4) was over before the clock had settled on a
+    fresh box: the 20 timed steps of the driver's command (8 ms) then sat on the ramp.  The reference's own protocol
+    is the same idea -- the first call pays the warm-up, the second is quoted (results/advect.pgiacc.17.7:2-13)."""
+    info = {"rule": "groups of 8 cold launches until 3 consecutive group means agree within 1 %",
+            "cap_ms": cap_ms, "min_ms": min_ms, "ms_used": 0.0, "groups": 0, "plateau_reached": None,
+            "group_ms_per_launch": []}
+    if cap_ms <= 0 or prewarm_launch is None:
+        return info
+    t0 = time.perf_counter()
+    n, groups = 0, []
+    while True:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            prewarm_launch(n)
+            n += 1
+        e1.record()
+        torch.cuda.synchronize()
+        groups.append(e0.elapsed_time(e1) / 8)
+        used = (time.perf_counter() - t0) * 1e3
+        last = groups[-3:]
+        if len(last) == 3 and used >= min_ms and max(last) - min(last) <= 0.01 * min(last):
+            info["plateau_reached"] = True
+            break
+        if used >= cap_ms:
+            info["plateau_reached"] = False
+            break
+    info.update(ms_used=used, groups=len(groups), group_ms_per_launch=[round(g, 5) for g in groups[-12:]])
+    return info
+
+
 def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=None, collective=True):
     """W untimed warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier +
     synchronize, with ONE pair of HIP events on the launch stream around the K launches (kernel
@@ -454,14 +497,14 @@ def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=Non
     its own K steps, and main() takes the maximum over the ranks in the one all-reduce that every
     rank reaches whether its block raised or not (a rank that raises between two barriers would
     leave the others waiting until the driver's timeout)."""
-    if PREWARM_MS > 0 and prewarm_launch is not None:   # GPU wake-up (clock / power-state ramp)
-        t_end = time.perf_counter() + PREWARM_MS * 1e-3
-        n = 0
-        while time.perf_counter() < t_end:
-            for _ in range(8):
-                prewarm_launch(n)
-                n += 1
-            torch.cuda.synchronize()
+    wake = wake_up(torch, prewarm_launch, PREWARM_MS, PREWARM_MIN_MS)
+    if world > 1 and collective:
+        # the ranks reach their plateaus at different times; the ones that were first would sit idle in the barrier
+        # in front of the timed region and start it on the clock ramp again.  So: meet here, then a SHORT second
+        # wake-up (same rule, at most 100 ms) that every rank starts at the same moment
+        torch.cuda.synchronize()
+        dist_mod.barrier()
+        wake["after_barrier"] = wake_up(torch, prewarm_launch, min(PREWARM_MS, 100.0), 0.0)
     for i in range(warmup):
         launch(-1 - i)
     if CURRENT_BLOCK[0] is not None:
@@ -495,14 +538,15 @@ def timed_loop(torch, dist_mod, world, launch, steps, warmup, prewarm_launch=Non
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist_mod.get_backend() == "nccl" else "cpu")
         dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, KernelTimes(k_avg, samples)
+    return dt, KernelTimes(k_avg, samples, wake)
 
 
 class KernelTimes(list):
-    """per-step event samples (list) + the mean over the timed region (`avg`)"""
-    def __init__(self, avg, samples):
+    """per-step event samples (list) + the mean over the timed region (`avg`) + what the wake-up did"""
+    def __init__(self, avg, samples, wake=None):
         super().__init__(samples)
         self.avg = avg
+        self.wake = wake
 
 
 MAX_COLD_SETS = 48   # distinct field sets the timed steps cycle through (each 1.6 GB at configs[2]: far past the 256-MB Infinity Cache)
@@ -695,7 +739,12 @@ def roofline_block(alg_bytes, kms, extra=None):
     r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
          "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": k_avg,
          "kernel_ms_note": "HIP events around the K timed launches / K; min / median: event pair per launch, separate pass",
-         "kernel_ms_min": min(kms), "kernel_ms_median": statistics.median(kms)}
+         "kernel_ms_min": min(kms), "kernel_ms_median": statistics.median(kms),
+         "kernel_ms_samples": [round(x, 5) for x in kms],
+         "avg_over_median": k_avg / statistics.median(kms)}
+    wake = getattr(kms, "wake", None)
+    if wake is not None:
+        r["wake_up"] = wake
     if extra:
         r.update(extra)
     return r
@@ -712,11 +761,50 @@ def traffic_lookup(key):
         return None
 
 
+def self_launch(ngpus):
+    """`python3 bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks
+    ourselves, as the reference starts its whole run with one command (`./advect`, mmf-mpdata-tracer/README.md:20-21).
+    This process has not imported torch and never touches a GPU: it starts `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <a free port> bench.py <the same arguments>`
+    as a CHILD process (never an exec: a process that has initialised the GPU must not be replaced, and the ranks
+    are children of the launcher anyway), lets it write straight to our stdout / stderr, hands SIGTERM / SIGINT on
+    to it and returns its exit code.  Nothing is retried: a failed attempt ends with the child's error output and
+    its non-zero code."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a port the OS hands out
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (this pool's host driver: dmabuf IPC only)
+    env["MPDATA_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print("BENCH_SELF_LAUNCH " + " ".join(cmd), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env)
+
+    def forward(signum, frame):
+        try:
+            child.send_signal(signum)
+        except OSError:
+            pass
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, forward)
+    while True:
+        try:
+            return child.wait()
+        except KeyboardInterrupt:
+            continue
+
+
 def main():
-    global ALIGNED, PREWARM_MS
+    global ALIGNED, PREWARM_MS, PREWARM_MIN_MS
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     ALIGNED = args.aligned
-    PREWARM_MS = args.prewarm_ms
+    PREWARM_MS, PREWARM_MIN_MS = args.prewarm_ms, min(args.prewarm_min_ms, args.prewarm_ms)
     life = Lifeline()
     import numpy as np
     import torch
@@ -728,9 +816,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and world == 1:    # (WORLD_SIZE=1 set by hand; main() starts the ranks itself when it is unset)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # MPDATA_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- exercises the N > 1
@@ -842,8 +929,13 @@ def main():
                        "cold": "every timed step runs on a plan of its own: own f, u, w, rho, rhow, adz (no byte of a "
                                "launch was touched by the previous one)" if not info["uw_shared_across_steps"] else
                                "NO: the field sets share u, w",
-                       "prewarm_ms": args.prewarm_ms,
-                       "prewarm": "wake-up launches cycle through the scratch field sets (cold, like the timed ones)",
+                       "prewarm_ms_cap": args.prewarm_ms, "prewarm_ms_used": kms.wake["ms_used"],
+                       "prewarm_plateau_reached": kms.wake["plateau_reached"],
+                       "prewarm": "wake-up launches cycle through the scratch field sets (cold, like the timed ones) "
+                                  "until three consecutive groups of 8 agree within 1 % (roofline.wake_up)",
+                       "launched_by": "bench.py itself (child torch.distributed.run)" if
+                                      os.environ.get("MPDATA_BENCH_SELF_LAUNCHED") == "1" else
+                                      ("torch.distributed.run" if world > 1 else "single process"),
                        "parallelism": f"ncrms-sharded x{world}, no data-path collective",
                        "ranks_seen": ranks_seen, "devices_seen": devices_seen},
             "roofline": roofline_block(alg_bytes, kms, {

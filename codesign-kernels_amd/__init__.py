@@ -12,10 +12,10 @@ is missing or no device is usable, calls raise.
 from .capi import (EINVAL, EUNSUPPORTED, ESTATE, ECOMM, LAYOUT_REFERENCE, LAYOUT_WAVEMAJOR, MpdataError, Plan, VARIANT_EXACT, VARIANT_FAST, advect_scalar2D,
                    advect_scalar2D_host, release_host_buffers, algorithmic_bytes, build_library, debug_stages, device_count,
                    empty_staggered, fill_synthetic, get_variant, host_shapes, lib, lib_path, pack_shard,
-                   set_plan_layout, set_serpentine, set_tile, set_variant, set_wm_flags, version, WMF_NOSTREAM, WMF_TPW1, WMF_NOSPLIT, shard_range, shapes, stage_shapes, stream_ceiling, unpack_shard)
+                   set_plan_layout, set_serpentine, set_tile, set_variant, set_wm_flags, version, WMF_NOSTREAM, WMF_TPW1, WMF_NOSPLIT, WMF_SPLIT, shard_range, shapes, stage_shapes, stream_ceiling, unpack_shard)
 from .shard import gather_outputs, partition, scatter_inputs
 
-__all__ = ["EINVAL", "EUNSUPPORTED", "ESTATE", "ECOMM", "set_serpentine", "set_wm_flags", "version", "WMF_NOSTREAM", "WMF_TPW1", "WMF_NOSPLIT", "LAYOUT_REFERENCE", "LAYOUT_WAVEMAJOR", "host_shapes", "set_plan_layout", "shard_range", "stream_ceiling", "MpdataError", "Plan", "VARIANT_EXACT", "VARIANT_FAST", "advect_scalar2D",
+__all__ = ["EINVAL", "EUNSUPPORTED", "ESTATE", "ECOMM", "set_serpentine", "set_wm_flags", "version", "WMF_NOSTREAM", "WMF_TPW1", "WMF_NOSPLIT", "WMF_SPLIT", "LAYOUT_REFERENCE", "LAYOUT_WAVEMAJOR", "host_shapes", "set_plan_layout", "shard_range", "stream_ceiling", "MpdataError", "Plan", "VARIANT_EXACT", "VARIANT_FAST", "advect_scalar2D",
            "advect_scalar2D_host", "release_host_buffers", "algorithmic_bytes", "build_library", "debug_stages", "device_count",
            "empty_staggered", "fill_synthetic", "get_variant", "lib", "lib_path", "pack_shard", "set_tile",
            "set_variant", "shapes", "stage_shapes", "unpack_shard", "partition", "scatter_inputs",

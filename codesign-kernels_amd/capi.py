@@ -167,7 +167,7 @@ def get_variant():
     return lib().mpdata_get_variant()
 
 
-WMF_NOSTREAM, WMF_TPW1, WMF_NOSPLIT = 1, 2, 4
+WMF_NOSTREAM, WMF_TPW1, WMF_NOSPLIT, WMF_SPLIT = 1, 2, 4, 8
 
 
 def set_serpentine(on):

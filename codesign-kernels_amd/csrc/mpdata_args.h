@@ -51,12 +51,16 @@ struct MpdataWmArgsT {
   R* wpark;                // EXACT only, may be null: park array of the limited vertical fluxes [tracer][tile][nx][64]
                            // (bit-identical flux: the finishing kernel adds them in the reference's order)
   unsigned long long* dbg; // diagnostic builds only (-DMPDWM_STAMPS): 8 words per wave (tools/wave_timeline.py); else null
+  int park_regs;           // EXACT only: 1 = park the limited vertical fluxes in REGISTERS (nx <= MPDATA_WM_NPK, one tracer per
+                           // wave; wpark is then null: no park array, no finishing kernel)
 };
 typedef MpdataWmArgsT<double> MpdataWmArgs;
+#define MPDATA_WM_NPK 36   // columns the register park of the EXACT wave-major kernels holds (six trips of six columns)
 // test switches of the wave-major launch (mpdata_set_wm_flags; MPDATA_WM_NOSTREAM / _TPW1 / _NOSPLIT)
 #define MPDATA_WMF_NOSTREAM 1   // run the batch form of the kernel on a single tracer as well
 #define MPDATA_WMF_TPW1 2       // tracer batches: one tracer per wave
-#define MPDATA_WMF_NOSPLIT 4    // an odd last tracer stays in the two-tracer launch
+#define MPDATA_WMF_NOSPLIT 4    // an odd last tracer stays in the two-tracer launch, as a two-tracer wave with an empty half
+#define MPDATA_WMF_SPLIT 8      // an odd last tracer goes through the one-tracer kernel behind the batch (rounds 2-4; A/B)
 
 // One tiling of the kernel template (W columns per thread, SPW strips per
 // wave, NWV waves per workgroup).

@@ -287,6 +287,12 @@ bool exact_flux_in_order() {
   static const bool sum = getenv("MPDATA_EXACT_FLUX") && !strcmp(getenv("MPDATA_EXACT_FLUX"), "sum");
   return !sum;
 }
+// ... and where they are parked: in REGISTERS where the kernel has a form for it (wave-major plans with nx <= MPDATA_WM_NPK:
+// no park array, no finishing kernel, round 5) unless MPDATA_EXACT_FLUX=hbm (round 4's park array everywhere; A/B)
+bool exact_flux_in_regs() {
+  static const bool hbm = getenv("MPDATA_EXACT_FLUX") && !strcmp(getenv("MPDATA_EXACT_FLUX"), "hbm");
+  return exact_flux_in_order() && !hbm;
+}
 // var: MPDATA_VARIANT_* (a plan passes the variant it was created with; < 0: the global one)
 template <typename R>
 int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u, const R* w,
@@ -443,7 +449,7 @@ int g_wm_flags = -1;
 int wm_flags() {
   if (g_wm_flags < 0)
     g_wm_flags = (getenv("MPDATA_WM_NOSTREAM") ? MPDATA_WMF_NOSTREAM : 0) | (getenv("MPDATA_WM_TPW1") ? MPDATA_WMF_TPW1 : 0) |
-                 (getenv("MPDATA_WM_NOSPLIT") ? MPDATA_WMF_NOSPLIT : 0);
+                 (getenv("MPDATA_WM_NOSPLIT") ? MPDATA_WMF_NOSPLIT : 0) | (getenv("MPDATA_WM_SPLIT") ? MPDATA_WMF_SPLIT : 0);
   return g_wm_flags;
 }
 int wm_wpb() { return 4; }
@@ -479,8 +485,9 @@ struct mpdata_plan {
   void* stage;                       // reference-layout staging: one tracer of f (or u, w)
   size_t stage_elems;
   void* flux_ref;                    // flux in the reference layout (level nz is carried through)
-  void* wpark;                       // EXACT: park array of the limited vertical fluxes (bit-identical flux), lazily allocated
-  size_t wpark_bytes;
+  void* wpark;                       // EXACT: park array of the limited vertical fluxes (bit-identical flux); with park_regs
+  size_t wpark_bytes;                // only mpdata_plan_run_uw needs it: allocated by its first call
+  bool park_regs;                    // EXACT, nx <= MPDATA_WM_NPK: mpdata_plan_run parks in registers (no park array)
   hipStream_t stream;
   bool own_stream;
   hipEvent_t ev0, ev1;
@@ -737,7 +744,8 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
     // EXACT: the park array of the limited vertical fluxes (bit-identical flux, see plan_flux_finish): [tracer][tile][nx][64]
     // 8-byte elements, the size of f's interior.  MPDATA_EXACT_FLUX=sum does without it (flux = upwind sum + limited sum,
     // <= 1e-13 relative, the behaviour up to round 3; a quarter faster in the EXACT variant).
-    if (e == hipSuccess && var == MPDATA_VARIANT_EXACT && exact_flux_in_order()) {
+    p->park_regs = var == MPDATA_VARIANT_EXACT && exact_flux_in_regs() && nx <= MPDATA_WM_NPK;
+    if (e == hipSuccess && var == MPDATA_VARIANT_EXACT && exact_flux_in_order() && !p->park_regs) {
       p->wpark_bytes = (size_t)ntracers * p->ntiles * (size_t)nx * 64 * 8;
       e = hipMalloc(&p->wpark, p->wpark_bytes);
       if (e != hipSuccess) {
@@ -885,7 +893,20 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
     a.u_ref = (const double*)u_ref; a.w_ref = (const double*)w_ref; a.ncrms = p->ncrms;
     a.dbg = g_dbg;   // (null unless a diagnostic build was handed a stamp buffer)
     // EXACT plans: the park array of the limited vertical fluxes (bit-identical flux; allocated with the plan)
-    a.wpark = p->wpark ? (double*)p->wpark + (long long)first * p->ntiles * ((long long)p->nx * 64) : nullptr;
+    a.park_regs = (p->park_regs && !u_ref) ? 1 : 0;
+    if (u_ref && p->park_regs && !p->wpark) {
+      // the kernel that reads u, w from the reference layout has no register-park form (its EXACT build takes every
+      // register it can get): the park array after all, allocated by the first such call
+      p->wpark_bytes = (size_t)p->ntracers * p->ntiles * (size_t)p->nx * 64 * 8;
+      const hipError_t e = hipMalloc(&p->wpark, p->wpark_bytes);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        p->wpark = nullptr;
+        return set_err((int)e, "mpdata_plan_run_uw (EXACT): no memory for the %.1f-GB park array of the bit-identical flux; "
+                               "MPDATA_EXACT_FLUX=sum does without it", p->wpark_bytes / 1e9);
+      }
+    }
+    a.wpark = (p->wpark && !a.park_regs) ? (double*)p->wpark + (long long)first * p->ntiles * ((long long)p->nx * 64) : nullptr;
     const bool fast = p->variant == MPDATA_VARIANT_FAST;
     if (u_ref) {
       a.reverse = 0;
@@ -1495,7 +1516,7 @@ int mpdata_set_variant(int v) {
 int mpdata_get_variant(void) { return variant(); }
 int mpdata_set_wm_flags(int flags) {
   const int prev = wm_flags();
-  if (flags >= 0) g_wm_flags = flags & (MPDATA_WMF_NOSTREAM | MPDATA_WMF_TPW1 | MPDATA_WMF_NOSPLIT);
+  if (flags >= 0) g_wm_flags = flags & (MPDATA_WMF_NOSTREAM | MPDATA_WMF_TPW1 | MPDATA_WMF_NOSPLIT | MPDATA_WMF_SPLIT);
   return prev;
 }
 int mpdata_set_serpentine(int on) {

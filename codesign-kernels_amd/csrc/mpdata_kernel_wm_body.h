@@ -47,6 +47,7 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "mpdata_args.h"
 
@@ -179,13 +180,34 @@ struct TileWm {
 // WRITES the u, w values it reads from the workgroup's ring into the plan's own u, w arrays (plan layout: its
 // lane's element of the column, the very offsets f's store uses) -- the first tracer of the batch is advected by
 // this kernel, and the batch kernel behind it finds the converted velocities without a conversion pass.
-template <typename R, int LPS, int WPB, bool STREAM, int TPW = 1, bool UWREF = false, bool UWCONV = false>
-__global__ void __launch_bounds__(64 * WPB, (TileWm<R, LPS, WPB, TPW, UWREF>::MIN_WAVES))
-mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
+// register park (wm_body, NPK > 0): PK[6 * trip + M - 5] = v with a compile-time index in every branch
+// (the empty asm statement keeps the optimiser from merging the branches' stores into ONE store through a selected
+//  pointer, which would turn the array into scratch memory)
+template <int IDX, typename R, int N> __device__ __forceinline__ void pk_set(R (&PK)[N], const R v) {
+  if constexpr (IDX >= 0 && IDX < N) {
+    PK[IDX] = v;
+    asm volatile("; park %0" ::"i"(IDX));
+  }
+}
+template <int M, typename R, int N, int... TT>
+__device__ __forceinline__ void pk_put(R (&PK)[N], const int trip, const R v, std::integer_sequence<int, TT...>) {
+  ((trip == TT ? pk_set<6 * TT + M - 5>(PK, v) : (void)0), ...);
+}
+
+// wm_body: everything one wave does for its (tile, first tracer `tr`) -- the body of the kernels below.  `lds` =
+// the workgroup's LDS, `my` = the wave's own ring inside it (the caller lays the rings out: a launch that mixes
+// the two-tracer and the one-tracer form gives every wave a two-tracer-sized ring).
+// NPK > 0 (EXACT, one tracer per wave, nx <= NPK; round 5): the lane's nx limited vertical fluxes are parked in NPK
+// REGISTERS instead of in HBM and added onto the finished upwind sum behind the march, in the reference's order
+// (:545, :624: bit-identical flux) -- no park array, no finishing kernel, no extra HBM bytes; 2 waves per SIMD.
+template <typename R, int LPS, int WPB, bool STREAM, int TPW = 1, bool UWREF = false, bool UWCONV = false, int NPK = 0>
+__device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds, R* const my, const int wave,
+                                        const unsigned tile, const unsigned tr, const unsigned ntr, const bool tile_ok) {
   using T = TileWm<R, LPS, WPB, TPW, UWREF>;
   static_assert(!UWCONV || UWREF, "UWCONV: the kernel that reads u, w from the reference layout");
   static_assert(TPW == 1 || (TPW == 2 && !STREAM), "two tracers per wave: batch form only");
   static_assert(!UWREF || (STREAM && TPW == 1), "u, w from the reference layout: one tracer per launch");
+  static_assert(NPK == 0 || (TPW == 1 && !UWREF && NPK % 6 == 0), "register park: one tracer per wave, whole trips of six columns");
   using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
   // T1X (FAST, one tracer per wave; fp64 and the two-instances-per-lane fp32 form): the 7-operation extrema and the ring sums of the two-tracer form
   // (XNEW, XSUM below: 6 operations per column fewer) in 128 VGPRs.  The registers come from: rho folded into
@@ -219,41 +241,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   // the reciprocal instead of two): +0.5 % on the headline.  (The fp32 forms spill with it.)
   constexpr bool CHAIN = std::is_same<R, double>::value;
   constexpr int SLP = T::SLP, RB = (int)sizeof(R);
-  __shared__ R lds[T::LDS_ELEMS];
 
   const int nx = a.nx, nz = a.nz, nzm = nz - 1;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  R* const my = lds + wave * (T::NS * T::SLOT);
-
-  // ---- wave -> (tile, tracer).  Workgroups are dealt to the 8 XCDs round-robin in dispatch
-  //      order.  Tracer batches: the waves that an XCD receives walk through the tracers of one
-  //      tile after the other, so the ntracers waves that share a tile's u, w, rho, ... run
-  //      back to back on ONE XCD and all but the first find them in that XCD's L2.
-  const unsigned ntr = (unsigned)a.ntracers;
-  unsigned tile, tr;
-  if (ntr == 1 && TPW == 1) {
-    tile = blockIdx.x * WPB + wave;
-    tr = 0;
-  } else {
-    const unsigned nxcd = 8, ntw = (ntr + TPW - 1) / TPW;   // waves per tile
-    const unsigned v = (blockIdx.x / nxcd) * WPB + wave;  // position in the XCD's wave sequence
-    tr = (v % ntw) * TPW;                                 // first tracer of the wave
-    tile = (v / ntw) * nxcd + blockIdx.x % nxcd;
-  }
-  // UWREF: the waves of a workgroup share the u, w ring (barriers, a share of the row fetches each):
-  // a wave beyond the last tile stays, works on an EMPTY f range (fetches deliver zeros, stores are
-  // dropped) and reads the constants of the last tile
-  bool tile_ok = true;
-  if constexpr (UWREF) {
-    tile_ok = tile < (unsigned)a.ntiles;
-    if (!tile_ok) tile = (unsigned)a.ntiles - 1u;
-  } else {
-    if (tile >= (unsigned)a.ntiles) return;  // (no barrier anywhere below)
-    // serpentine: every other run of a plan walks the tiles from the other end, so that it starts
-    // on what the previous run touched last (u, w and the like are still in the Infinity Cache)
-    if (a.reverse) tile = (unsigned)a.ntiles - 1u - tile;
-  }
 
 #ifdef MPDWM_STAMPS
   // diagnostic build (tools/wave_timeline.py): every wave records its start / end on the 100-MHz
@@ -336,7 +326,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   // complete: every lane parks its nx limited fluxes in [tracer][tile][column 1..nx][lane] (one 512-byte row per wave
   // and column step), stores the upwind sum alone as flux, and a finishing kernel (mpdata_capi.hip: flux_finish_kernel)
   // adds the parked terms in the reference's order.  FAST never parks (its flux is a sum in another order anyway).
-  constexpr bool CAN_PARK = !FASTV;
+  constexpr bool CAN_PARK = !FASTV && NPK == 0;
+  constexpr bool REG_PARK = !FASTV && NPK > 0;
+  [[maybe_unused]] R PK[NPK > 0 ? NPK : 1];   // REG_PARK: limited vertical flux of column i = PK[i - 1] (constant indices only: registers)
   [[maybe_unused]] const bool park = CAN_PARK && a.wpark != nullptr;
   [[maybe_unused]] const long long parkB = (long long)nx * 64 * RB;   // bytes of one (tracer, tile) block
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsp = v2::make_rsrc(
@@ -870,7 +862,13 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
         const V mxd = DN_C(MXN_2);
         const V mnd = DN_C(MNN_2);
         const V W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
-        if (CAN_PARK && park) park_st(q - 2, W3);   // (EXACT, bit-identical flux: added behind the march, in order)
+        if constexpr (REG_PARK) {
+          // column i = q - 2 = 6 * trip + M - 4 with M = (q + 2) mod 6 known at compile time (from the register-ring
+          // phase and the column of the pair): a wave-uniform branch on the trip number picks the register
+          constexpr int M = (PH * 4 + decltype(h_tag)::value * 3) % 6;
+          const int trip = (q + 2 - M) / 6;
+          pk_put<M>(PK, trip, W3, std::make_integer_sequence<int, NPK / 6 + 1>{});
+        } else if (CAN_PARK && park) park_st(q - 2, W3);   // (EXACT, bit-identical flux: added behind the march, in order)
         else if constexpr (UWREF || T1X) S1 = S1 + W3;  // one accumulator (two registers that kernel does not have)
         else S3 = S3 + W3;  // :624
         DW3_2 = UP_G(W3) - W3;
@@ -1020,7 +1018,12 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 
   if constexpr (TPW == 1) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
   {  // flux (:541-547, :624)
-    const V fl = ((UWREF || T1X) || (CAN_PARK && park)) ? S1 : S1 + S3;   // (parked: the upwind sum alone)
+    V fl = ((UWREF || T1X) || (CAN_PARK && park) || REG_PARK) ? S1 : S1 + S3;   // (parked: the upwind sum alone)
+    if constexpr (REG_PARK) {   // ... + www(1) + www(2) + ... + www(nx), one by one (:624)
+#pragma unroll
+      for (int i = 0; i < NPK; ++i)
+        if (i < nx) fl = fl + PK[i];
+    }
     int posf = pos;
     bool okf = lvl_ok;
     if constexpr (T1X || UWX2) {   // the lane's element, formed again behind the march: no register carries it through
@@ -1050,6 +1053,70 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 #endif
 }
 #undef MPDWM_WAIT
+
+// ---- wave -> (tile, first tracer).  Workgroups are dealt to the 8 XCDs round-robin in dispatch
+//      order.  Tracer batches: the waves that an XCD receives walk through the tracers of one
+//      tile after the other, so the waves that share a tile's u, w, rho, ... run
+//      back to back on ONE XCD and all but the first find them in that XCD's L2.
+template <int WPB, int TPW>
+__device__ __forceinline__ void wm_wave_to_tile(const unsigned ntr, const int wave, unsigned& tile, unsigned& tr) {
+  if (ntr == 1 && TPW == 1) {
+    tile = blockIdx.x * WPB + wave;
+    tr = 0;
+  } else {
+    const unsigned nxcd = 8, ntw = (ntr + TPW - 1) / TPW;   // waves per tile
+    const unsigned v = (blockIdx.x / nxcd) * WPB + wave;  // position in the XCD's wave sequence
+    tr = (v % ntw) * TPW;                                 // first tracer of the wave
+    tile = (v / ntw) * nxcd + blockIdx.x % nxcd;
+  }
+}
+
+template <typename R, int LPS, int WPB, bool STREAM, int TPW = 1, bool UWREF = false, bool UWCONV = false, int NPK = 0>
+__global__ void __launch_bounds__(64 * WPB, (NPK > 0 ? 2 : TileWm<R, LPS, WPB, TPW, UWREF>::MIN_WAVES))
+mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
+  using T = TileWm<R, LPS, WPB, TPW, UWREF>;
+  __shared__ R lds[T::LDS_ELEMS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntr = (unsigned)a.ntracers;
+  unsigned tile, tr;
+  wm_wave_to_tile<WPB, TPW>(ntr, wave, tile, tr);
+  // UWREF: the waves of a workgroup share the u, w ring (barriers, a share of the row fetches each):
+  // a wave beyond the last tile stays, works on an EMPTY f range (fetches deliver zeros, stores are
+  // dropped) and reads the constants of the last tile
+  bool tile_ok = true;
+  if constexpr (UWREF) {
+    tile_ok = tile < (unsigned)a.ntiles;
+    if (!tile_ok) tile = (unsigned)a.ntiles - 1u;
+  } else {
+    if (tile >= (unsigned)a.ntiles) return;  // (no barrier anywhere below)
+    // serpentine: every other run of a plan walks the tiles from the other end, so that it starts
+    // on what the previous run touched last (u, w and the like are still in the Infinity Cache)
+    if (a.reverse) tile = (unsigned)a.ntiles - 1u - tile;
+  }
+  wm_body<R, LPS, WPB, STREAM, TPW, UWREF, UWCONV, NPK>(a, lds, lds + wave * (T::NS * T::SLOT), wave, tile, tr, ntr, tile_ok);
+}
+
+// Tracer batches with an ODD number of tracers, one launch (round 5): the waves of a tile are its tracer pairs
+// (the two-tracer form) and, last, ONE wave that takes the odd tracer through the one-tracer batch form -- a
+// wave-uniform branch at kernel entry, 128-register code inside the 256-register allocation of the launch.  The odd
+// tracer runs beside its tile's pairs and finds u, w in its XCD's L2; as a launch of its own (rounds 2-4) it was 4 %
+// of the work for 5.4 % of the time and fetched u, w from HBM once more (traffic 1.056 x).  A two-tracer wave with an
+// empty second half in its place (MPDATA_WM_NOSPLIT) costs as much as a full one.
+template <typename R, int LPS, int WPB>
+__global__ void __launch_bounds__(64 * WPB, 2)
+mpdata_advect_wm_odd_kernel(const MpdataWmArgsT<R> a) {
+  using T2 = TileWm<R, LPS, WPB, 2, false>;
+  __shared__ R lds[T2::LDS_ELEMS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntr = (unsigned)a.ntracers;
+  unsigned tile, tr;
+  wm_wave_to_tile<WPB, 2>(ntr, wave, tile, tr);
+  if (tile >= (unsigned)a.ntiles) return;
+  if (a.reverse) tile = (unsigned)a.ntiles - 1u - tile;
+  R* const my = lds + wave * (T2::NS * T2::SLOT);
+  if (tr + 1 < ntr) wm_body<R, LPS, WPB, false, 2>(a, lds, my, wave, tile, tr, ntr, true);
+  else wm_body<R, LPS, WPB, false, 1>(a, lds, my, wave, tile, tr, ntr, true);
+}
 
 }  // namespace wm
 }  // namespace MPDATA_NS

@@ -88,6 +88,23 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
   // flags: MPDATA_WMF_* test switches (mpdata_args.h; mpdata_set_wm_flags / the MPDATA_WM_*
   // environment variables, read once by the C-ABI layer -- not in this timed launch path)
   const bool no_stream = flags & MPDATA_WMF_NOSTREAM, tpw1 = flags & MPDATA_WMF_TPW1, no_split = flags & MPDATA_WMF_NOSPLIT;
+#ifndef MPDATA_FAST_DIV
+  // EXACT, bit-identical flux without a park array (round 5): the nx limited vertical fluxes of a lane stay in
+  // REGISTERS (one tracer per wave, 2 waves per SIMD) and are added onto the finished upwind sum behind the march
+  if (a.park_regs && a.nx <= MPDATA_WM_NPK && !a.wpark) {
+    if (a.ntracers == 1 && !no_stream) {
+      const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);
+      hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, true, 1, false, false, MPDATA_WM_NPK>), dim3(blocks),
+                         dim3(64 * WPB), 0, (hipStream_t)stream, a);
+    } else {   // tracer batches: one tracer per wave, the per-XCD tracer walk
+      const long long per_xcd = ((long long)(a.ntiles + 7) / 8) * a.ntracers;
+      const unsigned blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
+      hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false, 1, false, false, MPDATA_WM_NPK>), dim3(blocks),
+                         dim3(64 * WPB), 0, (hipStream_t)stream, a);
+    }
+    return;
+  }
+#endif
   if (a.ntracers == 1 && no_stream) {
     const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);
     hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false>), dim3(blocks), dim3(64 * WPB), 0,
@@ -102,11 +119,14 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
     hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false>), dim3(blocks), dim3(64 * WPB), 0,
                        (hipStream_t)stream, a);
   } else {   // tracer batches: two tracers per wave
-    // An odd count: the last tracer goes through the one-tracer kernel behind the batch (a wave
-    // of the batch kernel with an empty second half costs as much as a full one: 4 % at 25
-    // tracers).  MPDATA_WM_NOSPLIT (tests): keep it in the batch launch.
+    // An odd count (round 5): ONE launch in which the last wave of every tile takes the odd tracer through the
+    // one-tracer batch form (mpdata_advect_wm_odd_kernel).  MPDATA_WM_SPLIT (A/B): the odd tracer through the
+    // one-tracer kernel BEHIND the batch, rounds 2-4 (4 % of the work, 5.4 % of the time, u and w fetched from HBM
+    // once more).  MPDATA_WM_NOSPLIT (tests): the odd tracer in a two-tracer wave with an empty second half (costs
+    // as much as a full one: 4 % at 25 tracers).
     MpdataWmArgsT<R> b = a;
-    const bool split = (a.ntracers & 1) && !no_split;
+    const bool odd = a.ntracers & 1;
+    const bool split = odd && (flags & MPDATA_WMF_SPLIT) && !no_split;
     if (split) b.ntracers = a.ntracers - 1;
     const long long per_xcd = ((long long)(b.ntiles + 7) / 8) * ((b.ntracers + 1) / 2);
     const unsigned blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
@@ -115,8 +135,12 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
     //  kernel's workgroups only get slots in the batch kernel's tail; removed again.  Round 4: a wave per TILE that
     //  walks through the tile's tracer pairs itself -- no slot-refill gap between pairs, zero spills, parity green --
     //  measured 7.58 ms against 7.32, profiles/r04_ablation.json: removed again.)
-    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false, 2>), dim3(blocks), dim3(64 * WPB), 0,
-                       (hipStream_t)stream, b);
+    if (odd && !split && !no_split)
+      hipLaunchKernelGGL((wm::mpdata_advect_wm_odd_kernel<R, LPS, WPB>), dim3(blocks), dim3(64 * WPB), 0,
+                         (hipStream_t)stream, b);
+    else
+      hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false, 2>), dim3(blocks), dim3(64 * WPB), 0,
+                         (hipStream_t)stream, b);
     if (split) {
       MpdataWmArgsT<R> c = a;
       c.f = a.f + (long long)(a.ntracers - 1) * a.f_tstride;
@@ -178,6 +202,7 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   a.tile_elems = a8.tile_elems; a.f_tstride = a8.f_tstride; a.flux_tstride = a8.flux_tstride; a.reverse = a8.reverse;
   a.u_ref = nullptr; a.w_ref = nullptr; a.ncrms = 0; a.dbg = a8.dbg;
   a.wpark = reinterpret_cast<v2::f32x2*>(a8.wpark);
+  a.park_regs = a8.park_regs;
 #define X(LPS_)                                \
   if (lps == LPS_) {                           \
     launch_wm_t<v2::f32x2, LPS_, MPDWM_WPB>(a, stream, flags); \

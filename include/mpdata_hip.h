@@ -274,9 +274,11 @@ int mpdata_get_variant(void);
  * on); returns the previous setting. */
 int mpdata_set_serpentine(int on);
 /* Test switches of the wave-major launch (bit 0: the batch form of the kernel for one tracer as
- * well, bit 1: one tracer per wave in tracer batches, bit 2: an odd last tracer stays in the
- * two-tracer launch; MPDATA_WM_NOSTREAM / MPDATA_WM_TPW1 / MPDATA_WM_NOSPLIT in the environment
- * set the initial value); flags < 0 only queries.  Returns the previous value. */
+ * well, bit 1: one tracer per wave in tracer batches, bit 2: an odd last tracer as a two-tracer
+ * wave with an empty half, bit 3: an odd last tracer through a launch of its own behind the batch
+ * -- the default takes it through one more wave per tile of the batch launch; MPDATA_WM_NOSTREAM /
+ * MPDATA_WM_TPW1 / MPDATA_WM_NOSPLIT / MPDATA_WM_SPLIT in the environment set the initial value);
+ * flags < 0 only queries.  Returns the previous value. */
 int mpdata_set_wm_flags(int flags);
 int mpdata_set_tile(int tile);            /* kernel tiling id; -1 = default */
 int mpdata_set_debug_buffer(void* dev_ptr); /* diagnostic builds only (-DMPDWM_STAMPS): per-wave stamp buffer */

@@ -1,5 +1,5 @@
-"""The measurement contract of the ONE JSON line bench.py prints, as checks on a parsed line: used on the recorded line
-(tests/test_bench_record.py, CPU) and on a line produced live on the GPU (tests/test_bench_live.py)."""
+"""The measurement contract of the ONE JSON line bench.py prints, as checks on a parsed line: used on a line
+produced live on the GPU (tests/test_bench_live.py)."""
 
 HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                  "scaling", "vs_baseline", "dtype", "data", "config", "roofline")
@@ -30,6 +30,12 @@ def check_roofline(d, ncrms, nx=32, nz=28):
     assert r["algorithmic_bytes_per_launch"] == ncrms * 8 * (nz - 1) * (4 * nx + 23)
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    # the per-launch list behind min / median is there, and so is what the wake-up did (plateau rule)
+    assert len(r["kernel_ms_samples"]) >= 1 and min(r["kernel_ms_samples"]) > 0
+    assert abs(min(r["kernel_ms_samples"]) - r["kernel_ms_min"]) < 1e-4
+    w = r["wake_up"]
+    assert w["cap_ms"] == d["config"]["prewarm_ms_cap"] and w["ms_used"] == d["config"]["prewarm_ms_used"]
+    assert w["plateau_reached"] in (True, False, None) and (w["groups"] >= 3 or w["cap_ms"] < 40 or not w["plateau_reached"])
     # the kernel cannot be faster than the step that contains it
     assert r["kernel_ms_avg"] <= d["ms_per_step"] * 1.001
     # HBM bytes from the PMC passes (a recorded profile, for the shapes that have one): at least the algorithmic

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_live_line_meets_the_contract():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-           "--prewarm-ms", "5", "--ncrms-per-gpu", "8192", "--batched-tracers", "3", "--batched-steps", "2",
+           "--prewarm-ms", "60", "--prewarm-min-ms", "10", "--ncrms-per-gpu", "8192", "--batched-tracers", "3", "--batched-steps", "2",
            "--no-fp32", "--no-bwk", "--no-host-call"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
@@ -27,6 +27,9 @@ def test_live_line_meets_the_contract():
     C.check_cpu_baseline(d)
     C.check_no_block_failed(d)
     assert d["steps"] == 4 and d["warmup"] == 2
+    w = d["roofline"]["wake_up"]        # the plateau rule ran: whole groups of 8, not longer than its cap + one group
+    assert w["groups"] >= 3 and 10.0 <= w["ms_used"] < 200.0 and len(w["group_ms_per_launch"]) >= 3
+    assert d["config"]["launched_by"] == "single process"
     # the headline on stderr is the headline of the line
     early = [ln for ln in res.stderr.splitlines() if ln.startswith("BENCH_HEADLINE {")]
     assert len(early) == 1 and json.loads(early[0].split(" ", 1)[1])["value"] == d["value"]

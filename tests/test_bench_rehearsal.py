@@ -1,7 +1,12 @@
 """The N > 1 control flow of bench.py (barriers, max-over-ranks time, rank-0 JSON line) rehearsed
 with two processes.  RCCL refuses two ranks on one device, so the rehearsal mode puts both ranks
 on cuda:0 over gloo (MPDATA_BENCH_REHEARSAL=1); the numbers mean nothing, the plumbing is the
-same code the driver runs with --gpus N."""
+same code the driver runs with --gpus N.
+
+The command is the PLAIN one -- `python3 bench.py --gpus 2 ...`, no launcher in the test: bench.py
+starts its ranks itself (bench.self_launch: a child `torch.distributed.run`, before torch is imported
+and before anything has touched the GPU).  One test keeps the other way in (the ranks started by
+torch.distributed.run around bench.py, WORLD_SIZE set)."""
 import json
 import os
 import subprocess
@@ -12,21 +17,42 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _two_ranks(extra_env=None, extra_args=(), rc0=True):
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a port the OS hands out
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+def _two_ranks(extra_env=None, extra_args=(), rc0=True, launcher=False):
     env = dict(os.environ, MPDATA_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--ncrms-per-gpu", "4096",
-           "--batched-tracers", "3", "--batched-steps", "2", "--no-fp32", "--no-bwk", "--no-cpu-baseline", *extra_args]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):      # (the plain command: nothing has started ranks for it)
+        env.pop(k, None)
+    cmd = [sys.executable]
+    if launcher:
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a port the OS hands out
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py"),
+            "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--ncrms-per-gpu", "4096",
+            "--batched-tracers", "3", "--batched-steps", "2", "--no-fp32", "--no-bwk", "--no-cpu-baseline", *extra_args]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert (res.returncode == 0) == rc0, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout                     # rank 0 only
     return json.loads(lines[0]), res
+
+
+@pytest.mark.gpu
+def test_plain_command_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` as the driver types it: ONE line, two ranks seen, rc 0."""
+    d, res = _two_ranks(extra_args=("--headline-only",))
+    assert "BENCH_SELF_LAUNCH " in res.stderr and "torch.distributed.run" in res.stderr
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and len(d["config"]["devices_seen"]) == 2
+    assert "bench.py itself" in d["config"]["launched_by"] and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_ranks_started_by_the_launcher_around_bench():
+    d, res = _two_ranks(extra_args=("--headline-only",), launcher=True)
+    assert "BENCH_SELF_LAUNCH" not in res.stderr
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["launched_by"] == "torch.distributed.run"
 
 
 @pytest.mark.gpu

@@ -128,18 +128,22 @@ def test_batch_form_of_the_kernel_on_single_tracers(M, oracle, monkeypatch, shap
 @pytest.mark.parametrize("shape", [(64, 32, 28), (37, 32, 17), (21, 33, 33), (10, 6, 64), (130, 31, 12), (7, 2, 4)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("ntr", [2, 3, 7])
-@pytest.mark.parametrize("mode", ["exact", "fast", "exact-one-tracer-per-wave", "exact-odd-tracer-in-the-batch"])
+@pytest.mark.parametrize("mode", ["exact", "fast", "exact-one-tracer-per-wave", "exact-odd-tracer-in-the-batch",
+                                  "exact-odd-tracer-behind-the-batch", "fast-odd-tracer-behind-the-batch"])
 def test_tracer_batches_two_tracers_per_wave(M, oracle, monkeypatch, shape, ntr, mode):
     """Tracer batches run TWO tracers per wave (u, w and the tracer-independent factors formed once
-    for both); the last tracer of an odd count goes
-    through the one-tracer kernel, or -- with the NOSPLIT launch switch -- stays in the batch launch paired with
-    an empty buffer range.  Every tracer must equal a single-tracer call of the oracle, on all lane mappings
+    for both); the last tracer of an odd count is taken by ONE more wave per tile of the same launch, through the
+    one-tracer form of the body (round 5: mpdata_advect_wm_odd_kernel) -- or, with the SPLIT launch switch, goes
+    through the one-tracer kernel behind the batch (rounds 2-4), or, with NOSPLIT, stays in a two-tracer wave
+    paired with an empty buffer range.  Every tracer must equal a single-tracer call of the oracle, on all lane mappings
     (nz <= 8 / 16 / 32 / 64) and ragged tile counts.  The TPW1 switch keeps the one-tracer-per-wave batch kernel
     covered."""
     if mode.endswith("per-wave"):
         M.set_wm_flags(M.WMF_TPW1)
     if mode.endswith("in-the-batch"):
         M.set_wm_flags(M.WMF_NOSPLIT)
+    if mode.endswith("behind-the-batch"):
+        M.set_wm_flags(M.WMF_SPLIT)
     var = M.VARIANT_FAST if mode.startswith("fast") else M.VARIANT_EXACT
     M.set_variant(var)
     ncrms, nx, nz = shape
