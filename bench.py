@@ -66,6 +66,7 @@ def parse():
                     help="f64: the headline (BASELINE.json fp64); f32: the reference's precision switch")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 side measurement")
     ap.add_argument("--no-bwk", action="store_true", help="skip the biharmonic_wk_scalar side measurement")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact_variant side block (EXACT: plan run, 25 tracers, device call)")
     ap.add_argument("--aligned", action="store_true",
                     help="allocate f, u, w with equally aligned bases (plain torch.empty) instead of the "
                          "staggered placement (DESIGN.md 4.4: 8 %% slower at ncrms=65536)")
@@ -1150,6 +1151,48 @@ def main():
                     "note": "rank 0's own shard and time", "roofline": roofline_block(ab, kms3)}}
         return dt5, entry
 
+    # the EXACT variant -- what a caller of the library gets who sets nothing (the library's and the Fortran driver's
+    # default: f AND flux bit-identical to the reference): plan run with 1 and with 25 tracers, reference-layout
+    # device call; cold like the headline, fewer steps
+    def b_exact():
+        M.set_variant(M.VARIANT_EXACT)
+        try:
+            es = min(steps, 20)
+            dt1, k1, i1 = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, 1, es,
+                                     SIDE_WARMUP, args.dist, npdt, tdt, 0.4 * mem_frac)
+            bt, bs = args.batched_tracers, min(steps, 6)
+            dt25, k25, i25 = bench_plan(M, torch, dist, world, dev, shared, sh_f1, n_loc, n_glob, sl0, nx, nz, bt, bs,
+                                        2, args.dist, npdt, tdt, 0.6 * mem_frac)
+            nb = 12
+            fs = []
+            for b in range(nb):
+                f = alloc(sh["f"], "f")
+                M.fill_synthetic(f, "f", 100 + b, args.dist, ncrms_global=n_glob, sl0=sl0)
+                fs.append(f)
+
+            def launch_ref(i):
+                M.advect_scalar2D(fs[i % nb], shared["u"], shared["w"], shared["rho"], shared["rhow"], shared["flux"], shared["adz"])
+            dtr, kr = timed_loop(torch, dist, world, launch_ref, es, SIDE_WARMUP, prewarm_launch=launch_ref, collective=False)
+            del fs
+        finally:
+            M.set_variant(M.VARIANT_FAST if args.variant == "fast" else M.VARIANT_EXACT)
+
+        def entry(dtm):
+            return {
+                "workload": "the headline protocol in the EXACT variant (-ffp-contract=off, IEEE divisions; f and flux "
+                            "bit-identical to the reference: the limited vertical fluxes of a lane are kept in registers "
+                            "and added onto the finished upwind sum in the reference's order, :545, :624)",
+                "value": cells_1 * es / dtm, "unit": "cell-updates/s", "steps": es, "ms_per_step": dtm / es * 1e3,
+                "roofline": roofline_block(alg_bytes, k1),
+                "tracer_batched": {"tracers": bt, "steps": bs, "value": n_loc * nx * (nz - 1) * bt * bs / dt25,
+                                   "ms_per_step": dt25 / bs * 1e3, "note": "rank 0's own shard and time",
+                                   "roofline": roofline_block(M.algorithmic_bytes(n_loc, nx, nz, bt), k25)},
+                "reference_layout_device_call": {"value": n_loc * nx * (nz - 1) * es / dtr, "ms_per_step": dtr / es * 1e3,
+                                                 "note": "rank 0's own shard and time; the park array of this kernel family "
+                                                         "is allocated and freed in stream order around every call",
+                                                 "roofline": roofline_block(alg_bytes, kr)}}
+        return dt1, entry
+
     # end to end: the drop-in call on HOST arrays, H2D + kernel + D2H -- never `value`; N = 1 only
     def b_host_call():
         host = {}
@@ -1204,6 +1247,8 @@ def main():
             side("reference_layout_device_call", b_reflayout)
         if not args.no_fp32 and not f32 and one:
             side("fp32", b_fp32)
+        if not args.no_exact and not f32 and one and args.variant == "fast":
+            side("exact_variant", b_exact)
         if world == 1 and not args.no_host_call and not f32 and one:
             side("end_to_end_host_call", b_host_call, rank0_only=True)
         if not args.no_bwk and not f32 and one:

@@ -33,5 +33,8 @@ def test_live_line_meets_the_contract():
     # the headline on stderr is the headline of the line
     early = [ln for ln in res.stderr.splitlines() if ln.startswith("BENCH_HEADLINE {")]
     assert len(early) == 1 and json.loads(early[0].split(" ", 1)[1])["value"] == d["value"]
-    for blk in ("step_with_fresh_uw", "twice_the_instances", "tracer_batched", "reference_layout_device_call"):
+    for blk in ("step_with_fresh_uw", "twice_the_instances", "tracer_batched", "reference_layout_device_call",
+                "exact_variant"):
         assert d[blk]["value"] > 0 and 0 < d[blk]["roofline"]["frac"] < 1, blk
+    ex = d["exact_variant"]     # the variant a default caller gets has a number of its own: plan run, batch, device call
+    assert ex["tracer_batched"]["value"] > 0 and ex["reference_layout_device_call"]["value"] > 0

@@ -196,7 +196,7 @@ def test_bench_on_two_real_gpus_with_the_plain_command():
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
                           "--ncrms-per-gpu", "16384", "--batched-tracers", "3", "--batched-steps", "2", "--no-fp32",
-                          "--no-bwk", "--no-x2", "--no-shared-block"],
+                          "--no-bwk", "--no-x2", "--no-shared-block", "--no-exact"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
