@@ -51,6 +51,7 @@ struct MpdataWmArgsT {
   R* wpark;                // EXACT only, may be null: park array of the limited vertical fluxes [tracer][tile][nx][64]
                            // (bit-identical flux: the finishing kernel adds them in the reference's order)
   unsigned long long* dbg; // diagnostic builds only (-DMPDWM_STAMPS): 8 words per wave (tools/wave_timeline.py); else null
+  int nkw;                 // nz > 64 (kernel form LPS = 128): waves per instance and tracer, 1 + ceil((nz - 64) / 58); else 1
   int park_regs;           // EXACT only: 1 = park the limited vertical fluxes in REGISTERS (nx <= MPDATA_WM_NPK, one tracer per
                            // wave; wpark is then null: no park array, no finishing kernel)
 };

@@ -531,7 +531,11 @@ MpdataLayoutJob wm_job(const mpdata_plan* p, int which, void* ref, int first_tra
   return j;
 }
 
-int wm_lps_for(int nz) { return nz <= 8 ? 8 : nz <= 16 ? 16 : nz <= 32 ? 32 : nz <= 64 ? 64 : 0; }
+// lanes per instance of the wave-major kernels; 128 = an instance wider than a wave (65 <= nz <= 127: several waves
+// per instance, mpdata_kernel_wm_body.h "KS"; the layout kernels hold a column of one instance group in LDS: nzm <= 126)
+#define MPDATA_WM_NZ_MAX 127
+int wm_lps_for(int nz) { return nz <= 8 ? 8 : nz <= 16 ? 16 : nz <= 32 ? 32 : nz <= 64 ? 64 : nz <= MPDATA_WM_NZ_MAX ? 128 : 0; }
+int wm_nkw_for(int nz) { return nz <= 64 ? 1 : 1 + (nz - 64 + 57) / 58; }
 
 int plan_check(const mpdata_plan* p, int eb) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
@@ -683,7 +687,10 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   if (rc) return rc;
   const int var = variant();
   // wave-major: fp64, and fp32 with an even ncrms (two adjacent instances per lane = 8-byte elements)
-  const bool wmaj = (eb == 8 || (ncrms & 1) == 0) && wm_lps_for(nz) != 0 &&
+  // (nz > 64: fp64; EXACT with the flux in the reference's order needs the register park there: nx <= MPDATA_WM_NPK)
+  const bool ks_ok = nz <= 64 || (eb == 8 && (var != MPDATA_VARIANT_EXACT || !exact_flux_in_order() ||
+                                              (exact_flux_in_regs() && nx <= MPDATA_WM_NPK)));
+  const bool wmaj = (eb == 8 || (ncrms & 1) == 0) && wm_lps_for(nz) != 0 && ks_ok &&
                     plan_layout_default() == MPDATA_LAYOUT_WAVEMAJOR && tile_override() < 0;
   MpdataTileInfo t;
   if (!wmaj) {
@@ -711,7 +718,7 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
     const int nzm = nz - 1;
     const int web = 8;   // bytes of an element on the wave-major side (fp32: a pair of instances)
     p->wm_ncrms = eb == 8 ? ncrms : ncrms / 2;
-    p->lps = wm_lps_for(nz); p->slp = 64 / p->lps; p->wpb = wm_wpb();
+    p->lps = wm_lps_for(nz); p->slp = p->lps >= 64 ? 1 : 64 / p->lps; p->wpb = wm_wpb();
     p->ntiles = (int)((p->wm_ncrms + p->slp - 1) / p->slp);
     p->chunk = (long long)p->slp * nzm;
     p->main_e = p->chunk * web / 128 * (128 / web);
@@ -721,7 +728,7 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
     // non-empty: 128 <= main part <= 384 bytes.  True for every (LPS, nz) the kernels are built for
     // (chunk = (64/LPS) * nzm * 8 bytes with LPS/2 <= nzm < LPS, nz >= 3: 128 .. 504 bytes); checked
     // here so that a future tiling cannot break the wait silently.
-    if (p->main_e * web < 128 || p->main_e * web > 384) {
+    if (p->lps <= 64 && (p->main_e * web < 128 || p->main_e * web > 384)) {   // (nz > 64: one fetch instruction per array and pair)
       free(p);
       return set_err(MPDATA_EUNSUPPORTED, "internal: column chunk of %lld bytes breaks the two-instructions-per-fetch "
                                           "invariant of the wave-major kernels", (long long)(p->chunk * web));
@@ -894,6 +901,7 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
     a.dbg = g_dbg;   // (null unless a diagnostic build was handed a stamp buffer)
     // EXACT plans: the park array of the limited vertical fluxes (bit-identical flux; allocated with the plan)
     a.park_regs = (p->park_regs && !u_ref) ? 1 : 0;
+    a.nkw = wm_nkw_for(p->nz);
     if (u_ref && p->park_regs && !p->wpark) {
       // the kernel that reads u, w from the reference layout has no register-park form (its EXACT build takes every
       // register it can get): the park array after all, allocated by the first such call

@@ -141,7 +141,17 @@ struct TileWm {
   static constexpr int XRG = LPS / 8;           // UWREF: groups of 8 rows (one DMA instruction) per array block
   static constexpr int XARR = LPS * GX;         // UWREF: elements of one (column, array) block: LPS rows x 16
   static constexpr int XSLOT = 4 * XARR;        // UWREF: a pair slot of the shared ring: [column of pair][u, w]
-  static constexpr int SLP = 64 / LPS;          // instances per wave = per tile
+  // LPS = 128 = "KS", nz > 64 (round 5): an instance is wider than a wave, so a.nkw = 1 + ceil((nz - 64) / 58)
+  // waves share it.  Wave h works on the 64 levels koff + 1 .. koff + 64 (koff = 58 h; the last wave: the even
+  // number >= nz - 64), lanes along the levels as ever, and nothing crosses between the waves: the routine's
+  // dependency cone has radius 3 in k, so a wave's results are right from its 4th level to
+  // its 61st (its 1st if that is level 1, its last real level if the wave holds level nzm), and those ranges
+  // tile the column: 58 h + 4 .. 58 h + 61.  The other six levels are computed twice -- 5 % of the lanes at
+  // nz = 72 ... 122 instead of a barrier and an LDS exchange at each of the four places of a column step where a
+  // level takes something from its neighbour.  The layout is the one-instance-per-tile layout (chunk = nzm elements).
+  static constexpr bool KS = LPS == 128;
+  static constexpr int LW = KS ? 64 : LPS;      // lanes of a wave per instance
+  static constexpr int SLP = 64 / LW;           // instances per wave = per tile
   static constexpr int WPB = WPB_;              // waves (= tiles) per workgroup; they never synchronise
   static constexpr int THREADS = 64 * WPB_;
   static constexpr int NZM_MAX = LPS - 1;       // lane k = nz is the ghost level (w = 0)
@@ -152,7 +162,8 @@ struct TileWm {
   static constexpr int UO = TPW_ * ARR, WO = (TPW_ + 1) * ARR;   // a slot: f of every tracer of the wave, u, w
   static constexpr int SLOT = UWREF_ ? ARR : (2 + TPW_) * ARR;   // (UWREF: the wave's own ring holds f only)
   static constexpr int LDS_ELEMS = WPB_ * NS * SLOT + (UWREF_ ? NS * XSLOT : 0);
-  static_assert(!UWREF_ || (WPB_ * (64 / LPS) == GX && TPW_ == 1), "UWREF: 16 instances per workgroup, one tracer per wave");
+  static_assert(!UWREF_ || (!KS && WPB_ * (64 / LW) == GX && TPW_ == 1), "UWREF: 16 instances per workgroup, one tracer per wave");
+  static_assert(!KS || TPW_ == 1, "nz > 64: one tracer per wave");
   // 128 VGPRs; one instance per wave (LPS = 64) carries the ghost-level select of w and gets 168
   // (two tracers per wave: twice the tracer state, 256 VGPRs, 2 waves per SIMD)
   // UWREF: 16 / SLP waves per workgroup.  FAST fits 128 VGPRs (two workgroups of 8 waves per CU at
@@ -163,7 +174,7 @@ struct TileWm {
 #else
   static constexpr int MIN_WAVES_X = 2;
 #endif
-  static constexpr int MIN_WAVES = UWREF_ ? MIN_WAVES_X : (TPW_ == 2 ? 2 : (LPS == 64 ? 3 : 4));
+  static constexpr int MIN_WAVES = UWREF_ ? MIN_WAVES_X : (TPW_ == 2 ? 2 : (LW == 64 ? 3 : 4));
   static_assert(sizeof(R_) == 8, "8-byte elements (double, or two fp32 instances per lane)");
 };
 
@@ -202,12 +213,16 @@ __device__ __forceinline__ void pk_put(R (&PK)[N], const int trip, const R v, st
 // (:545, :624: bit-identical flux) -- no park array, no finishing kernel, no extra HBM bytes; 2 waves per SIMD.
 template <typename R, int LPS, int WPB, bool STREAM, int TPW = 1, bool UWREF = false, bool UWCONV = false, int NPK = 0>
 __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds, R* const my, const int wave,
-                                        const unsigned tile, const unsigned tr, const unsigned ntr, const bool tile_ok) {
+                                        const unsigned tile, const unsigned tr, const unsigned ntr, const bool tile_ok,
+                                        const int kwave = 0) {
   using T = TileWm<R, LPS, WPB, TPW, UWREF>;
   static_assert(!UWCONV || UWREF, "UWCONV: the kernel that reads u, w from the reference layout");
   static_assert(TPW == 1 || (TPW == 2 && !STREAM), "two tracers per wave: batch form only");
   static_assert(!UWREF || (STREAM && TPW == 1), "u, w from the reference layout: one tracer per launch");
   static_assert(NPK == 0 || (TPW == 1 && !UWREF && NPK % 6 == 0), "register park: one tracer per wave, whole trips of six columns");
+  constexpr bool KS = T::KS;
+  constexpr int LW = T::LW;
+  static_assert(!KS || (!STREAM && TPW == 1 && !UWREF), "nz > 64: the batch form of the data movement (one fetch instruction per array and pair)");
   using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
   // T1X (FAST, one tracer per wave; fp64 and the two-instances-per-lane fp32 form): the 7-operation extrema and the ring sums of the two-tracer form
   // (XNEW, XSUM below: 6 operations per column fewer) in 128 VGPRs.  The registers come from: rho folded into
@@ -226,7 +241,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   // the 7-operation extrema (stage A below): where the registers allow it (the u, w-ring form with one instance per
   // wave, LPS = 64, and its converting form UWCONV are two registers short: they keep the merged ring value and take
   // the extrema as written)
-  constexpr bool XNEW = TPW == 2 || T1X || (UWX2 && LPS < 64 && !UWCONV);
+  constexpr bool XNEW = TPW == 2 || T1X || (UWX2 && LW < 64 && !UWCONV);
   // FAST, two tracers per wave (the VALU- / power-bound form): three operations per tracer and column fewer
   // by carrying sums in the rings and sharing the velocity parts of the upwind fluxes (below: XSUM)
   constexpr bool XSUM = FASTV && XNEW && !UWX2;
@@ -277,12 +292,18 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   R* const flux1 = has1 ? flux + a.flux_tstride : flux;
 
   // ---- lane -> (instance s, level k) -----------------------------------------
-  const int s_l = lane / LPS;
-  const int kk = lane % LPS;               // k - 1
+  const int s_l = lane / LW;
+  // KS: the wave's first level - 1.  58 kwave, but never past the (even) start from which the wave still reaches nz
+  int koff = 0;
+  if constexpr (KS) koff = min(58 * kwave, max(0, (nz - 64 + 1) & ~1));
+  const int kk = lane % LW + koff;         // k - 1
   const int k = kk + 1;
   const bool lvl_ok = k <= nzm;            // real level (else ghost / dead lane)
   const int kl = lvl_ok ? kk : nzm - 1;    // level index whose data the lane reads
   const int pos = s_l * nzm + kl;          // element of the chunk
+  // the levels whose results this wave stores (KS: the part of its 64 that is outside the cone of its artificial ends)
+  bool out_ok = lvl_ok;
+  if constexpr (KS) out_ok = lvl_ok && (kwave == 0 || k >= 58 * kwave + 4) && (kwave + 1 == a.nkw || k <= 58 * kwave + 61);
 
   // per-lane constants (:552, :553, :565, :569): the loads go out here, the arithmetic on them
   // follows the DMA prologue below (a wave's first column fetch must not queue behind a
@@ -304,9 +325,11 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   //      written with data (chunk <= 62: the lane that fetches it is out of range and delivers
   //      zeros with every pair; LPS = 64 selects w instead): with w = 0 the ghost level's fluxes are exact zeros, which is all the
   //      level below ever takes from it (www(:,:,:,nz) = 0, :511).
-  const R* const p_own = my + ((LPS == 64 || lvl_ok) ? pos : 63);
-  const R* const p_dn = my + (s_l * nzm + (kl > 0 ? kl - 1 : 0));
-  const R* const p_up = my + (s_l * nzm + (kl + 1 < nzm ? kl + 1 : nzm - 1));
+  // (KS: the LDS image of a column holds the wave's 64 levels; the first and the last lane of a wave that does not hold
+  //  level 1 / level nzm read themselves as their neighbour: they are inside the cone of the wave's artificial end)
+  const R* const p_own = my + ((LW == 64 || lvl_ok) ? pos - koff : 63);
+  const R* const p_dn = my + (s_l * nzm + max((kl > 0 ? kl - 1 : 0) - koff, 0));
+  const R* const p_up = my + (s_l * nzm + min((kl + 1 < nzm ? kl + 1 : nzm - 1) - koff, KS ? 63 : 1 << 30));
 
   // ---- global addressing: one descriptor per array, based at the wave's tile (32-bit offsets
   //      inside a tile, arrays of any size).  Element e of column c of the tile lives at
@@ -373,25 +396,25 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
     xv = ok ? (unsigned)((sl_src + lvl * row) * RB) : 0xFFFFFFF8u;
     x_dst = xa * T::XARR + xrg * 8 * T::GX;                      // element offset inside a [column] half slot
     // read positions: row = level index (ghost and dead lanes: the zero rows nzm .. LPS-1)
-    const int s_g = wave * SLP + lane / LPS;                     // instance inside the workgroup
+    const int s_g = wave * SLP + lane / LW;                      // instance inside the workgroup
     auto xpos = [&](const int r) __attribute__((always_inline)) {
       return r * T::GX + ((((s_g >> 1) ^ ((r >> 1) & 7)) << 1) | (s_g & 1));
     };
-    const int kk_ = lane % LPS;
+    const int kk_ = lane % LW;
     const bool real = kk_ < nzm;
     x_own = xring + xpos(kk_);
     x_dn = xring + xpos(kk_ > 0 ? kk_ - 1 : 0);
-    x_up = xring + xpos(real ? (kk_ + 1 < nzm ? kk_ + 1 : nzm - 1) : (kk_ + 1 < LPS ? kk_ + 1 : LPS - 1));
+    x_up = xring + xpos(real ? (kk_ + 1 < nzm ? kk_ + 1 : nzm - 1) : (kk_ + 1 < LW ? kk_ + 1 : LW - 1));
   }
   const unsigned posB = (unsigned)(pos * RB);
-  const unsigned st_main = (lvl_ok && posB < mainB) ? posB : OOB;               // the lane's element of a chunk:
-  const unsigned st_rem = (lvl_ok && posB >= mainB) ? remBase + (posB - mainB) : OOB;  // in one of the two parts
+  const unsigned st_main = (out_ok && posB < mainB) ? posB : OOB;               // the lane's element of a chunk:
+  const unsigned st_rem = (out_ok && posB >= mainB) ? remBase + (posB - mainB) : OOB;  // in one of the two parts
   [[maybe_unused]] const bool st_in_main = posB < mainB;
-  [[maybe_unused]] const unsigned st_ab = lvl_ok ? (st_in_main ? posB : remBase + (posB - mainB)) : OOB;
+  [[maybe_unused]] const unsigned st_ab = out_ok ? (st_in_main ? posB : remBase + (posB - mainB)) : OOB;
   // DMA source offsets of a pair instruction: lane L < 32 fetches bytes 16L.. of the even column,
   // lane L >= 32 bytes 16(L-32).. of the odd one (the LDS image keeps the two columns 512 B apart);
   // the lanes of a column's main part in the one instruction, those of its remainder in the other
-  const unsigned in_col = (unsigned)((lane & 31) * 16);
+  const unsigned in_col = (unsigned)((lane & 31) * 16 + koff * RB);   // (KS: the wave's 512 bytes of the column start at level koff + 1)
   const unsigned hi = lane >= 32 ? 1u : 0u;
   const bool lane_main = in_col < mainB;
   const unsigned vA = lane_main ? in_col + hi * mainB : OOB;
@@ -413,12 +436,12 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   unsigned dcur = lane_main ? vA : vB;
   // (the register-starved forms of the u, w-ring kernel: ONE register for both branches of the f fetch -- seen as a
   //  select of vA / vB the compiler keeps both)
-  if constexpr (UWREF && (LPS == 64 || UWCONV)) asm volatile("" : "+v"(dcur));
+  if constexpr (UWREF && (LW == 64 || UWCONV)) asm volatile("" : "+v"(dcur));
   // the two per-lane strides share one register: pair stride of the lane's DMA part in the low
   // half, column stride of its store part in the high half (both <= 1024); a stride is added with
   // the half-word select of the add itself (SDWA), so unpacking costs no instruction
   const unsigned pstride = dcur == OOB ? 0u : (lane_main ? 2u * mainB : 2u * remB);
-  const unsigned cstride = lvl_ok ? (posB < mainB ? mainB : remB) : 0u;
+  const unsigned cstride = out_ok ? (posB < mainB ? mainB : remB) : 0u;
   const unsigned strides = pstride | (cstride << 16);
   auto add_lo = [](const unsigned a, const unsigned packed) __attribute__((always_inline)) {
     unsigned r;
@@ -432,7 +455,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   };
   // store offset of column c = q - 1 of the step about to run; the march starts at q = -2, behind one
   // empty flush of the deferred-store slot, which advances the offset as well
-  unsigned scur = lvl_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) - (TPW == 1 ? 4u : 3u) * cstride : OOB;
+  unsigned scur = out_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) - (TPW == 1 ? 4u : 3u) * cstride : OOB;
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   // pair P of all three arrays into its ring slot.  e*/o*: which columns of the pair exist for
@@ -582,7 +605,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
     r.f0q = ldv(p_own + LO);
     r.uq = p_own[LO + T::UO];
     r.wq = p_own[LO + T::WO];
-    if constexpr (LPS == 64) r.wq = lvl_ok ? r.wq : R(0);
+    if constexpr (LW == 64) r.wq = lvl_ok ? r.wq : R(0);
     r.f0d = ldv(p_dn + LO);
     r.f0u = ldv(p_up + LO);
     r.ud = p_dn[LO + T::UO];
@@ -622,7 +645,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
       f0q = ldv(p_own + LO);
       uq = p_own[LO + T::UO];
       wq = p_own[LO + T::WO];
-      if constexpr (LPS == 64) wq = lvl_ok ? wq : R(0);
+      if constexpr (LW == 64) wq = lvl_ok ? wq : R(0);
     } else {
       f0q = in.f0q; uq = in.uq; wq = in.wq;
     }
@@ -1025,18 +1048,18 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
         if (i < nx) fl = fl + PK[i];
     }
     int posf = pos;
-    bool okf = lvl_ok;
-    if constexpr (T1X || UWX2) {   // the lane's element, formed again behind the march: no register carries it through
+    bool okf = out_ok;
+    if constexpr ((T1X || UWX2) && !KS) {   // the lane's element, formed again behind the march: no register carries it through
       unsigned z;
       asm volatile("s_mov_b32 %0, 0" : "=s"(z));
       const int l2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
-      const int kk2 = l2 % LPS;
+      const int kk2 = l2 % LW;
       okf = kk2 < nzm;
-      posf = (l2 / LPS) * nzm + (okf ? kk2 : nzm - 1);
+      posf = (l2 / LW) * nzm + (okf ? kk2 : nzm - 1);
     }
     if (okf && tile_ok) flux[posf] = first(fl);
     if constexpr (TPW == 2)
-      if (lvl_ok && has1) flux1[pos] = second(fl);
+      if (out_ok && has1) flux1[pos] = second(fl);
   }
 #ifdef MPDWM_STAMPS
   if (a.dbg) {
@@ -1058,15 +1081,21 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
 //      order.  Tracer batches: the waves that an XCD receives walk through the tracers of one
 //      tile after the other, so the waves that share a tile's u, w, rho, ... run
 //      back to back on ONE XCD and all but the first find them in that XCD's L2.
+// nkw (nz > 64 only, else 1): waves per instance and tracer; kwave = which of them this wave is
 template <int WPB, int TPW>
-__device__ __forceinline__ void wm_wave_to_tile(const unsigned ntr, const int wave, unsigned& tile, unsigned& tr) {
+__device__ __forceinline__ void wm_wave_to_tile(const unsigned ntr, const int wave, unsigned& tile, unsigned& tr,
+                                                const unsigned nkw = 1, int* kwave = nullptr) {
   if (ntr == 1 && TPW == 1) {
-    tile = blockIdx.x * WPB + wave;
+    const unsigned gw = blockIdx.x * WPB + wave;
+    tile = gw / nkw;
+    if (kwave) *kwave = (int)(gw % nkw);
     tr = 0;
   } else {
-    const unsigned nxcd = 8, ntw = (ntr + TPW - 1) / TPW;   // waves per tile
+    const unsigned nxcd = 8, ntw = ((ntr + TPW - 1) / TPW) * nkw;   // waves per tile
     const unsigned v = (blockIdx.x / nxcd) * WPB + wave;  // position in the XCD's wave sequence
-    tr = (v % ntw) * TPW;                                 // first tracer of the wave
+    const unsigned r = v % ntw;
+    tr = (r / nkw) * TPW;                                 // first tracer of the wave
+    if (kwave) *kwave = (int)(r % nkw);
     tile = (v / ntw) * nxcd + blockIdx.x % nxcd;
   }
 }
@@ -1079,7 +1108,9 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned ntr = (unsigned)a.ntracers;
   unsigned tile, tr;
-  wm_wave_to_tile<WPB, TPW>(ntr, wave, tile, tr);
+  int kwave = 0;
+  if constexpr (T::KS) wm_wave_to_tile<WPB, TPW>(ntr, wave, tile, tr, (unsigned)a.nkw, &kwave);
+  else wm_wave_to_tile<WPB, TPW>(ntr, wave, tile, tr);
   // UWREF: the waves of a workgroup share the u, w ring (barriers, a share of the row fetches each):
   // a wave beyond the last tile stays, works on an EMPTY f range (fetches deliver zeros, stores are
   // dropped) and reads the constants of the last tile
@@ -1093,7 +1124,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     // on what the previous run touched last (u, w and the like are still in the Infinity Cache)
     if (a.reverse) tile = (unsigned)a.ntiles - 1u - tile;
   }
-  wm_body<R, LPS, WPB, STREAM, TPW, UWREF, UWCONV, NPK>(a, lds, lds + wave * (T::NS * T::SLOT), wave, tile, tr, ntr, tile_ok);
+  wm_body<R, LPS, WPB, STREAM, TPW, UWREF, UWCONV, NPK>(a, lds, lds + wave * (T::NS * T::SLOT), wave, tile, tr, ntr, tile_ok, kwave);
 }
 
 // Tracer batches with an ODD number of tracers, one launch (round 5): the waves of a tile are its tracer pairs

@@ -153,8 +153,35 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
     }
   }
 }
+// nz > 64 (kernel form LPS = 128): a.nkw waves per instance and tracer, one tracer per wave, the batch form of the
+// data movement; EXACT with the register park (the caller makes sure that nx <= MPDATA_WM_NPK or that no flux order
+// is asked for)
+template <typename R>
+static void launch_wm_ks(const MpdataWmArgsT<R>& a, void* stream) {
+  constexpr int WPB = MPDWM_WPB;
+  unsigned blocks;
+  if (a.ntracers == 1) {
+    blocks = (unsigned)(((long long)a.ntiles * a.nkw + WPB - 1) / WPB);
+  } else {
+    const long long per_xcd = ((long long)(a.ntiles + 7) / 8) * a.ntracers * a.nkw;  // waves of one XCD
+    blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
+  }
+#ifndef MPDATA_FAST_DIV
+  if (a.park_regs && a.nx <= MPDATA_WM_NPK) {
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 1, false, false, MPDATA_WM_NPK>), dim3(blocks),
+                       dim3(64 * WPB), 0, (hipStream_t)stream, a);
+    return;
+  }
+#endif
+  hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 1>), dim3(blocks), dim3(64 * WPB), 0,
+                     (hipStream_t)stream, a);
+}
 bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags) {
   if (wpb != MPDWM_WPB) return false;
+  if (lps == 128) {
+    launch_wm_ks<double>(a, stream);
+    return true;
+  }
 #define X(LPS_)                             \
   if (lps == LPS_) {                        \
     launch_wm_t<double, LPS_, MPDWM_WPB>(a, stream, flags); \
@@ -203,6 +230,7 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   a.u_ref = nullptr; a.w_ref = nullptr; a.ncrms = 0; a.dbg = a8.dbg;
   a.wpark = reinterpret_cast<v2::f32x2*>(a8.wpark);
   a.park_regs = a8.park_regs;
+  a.nkw = 1;
 #define X(LPS_)                                \
   if (lps == LPS_) {                           \
     launch_wm_t<v2::f32x2, LPS_, MPDWM_WPB>(a, stream, flags); \

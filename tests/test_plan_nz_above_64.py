@@ -1,0 +1,189 @@
+"""nz > 64 behind the plan API (round 5; the reference's nz is a compile-time parameter of the routine, reference :8 --
+CRMs with more than 64 levels exist).  An instance is then wider than a wave: 1 + ceil((nz - 64) / 58) waves share
+it, each on 64 levels of its own, NOTHING crosses between them -- the routine's dependency cone has radius 3 in k
+(SURVEY.md 8 a14), so a wave's results are right from its 4th to its 61st level and those ranges tile the column
+(csrc/mpdata_kernel_wm_body.h, kernel form LPS = 128).  Up to round 4 such plans fell back to the k-marching kernel
+of round 1 (10-30 % of the headline's rate).
+
+Bars as everywhere: EXACT f AND flux bit-identical to the oracle (flux through the register park: nx <= 36),
+FAST max|d| < 1e-12 on conditioned inputs; the output contract on the whole arrays."""
+import numpy as np
+import pytest
+
+from util import max_abs, to_dev, to_host
+
+pytestmark = pytest.mark.gpu
+
+# nz: the first size of the form (65), seams at every parity (koff of the last wave = the even number >= nz - 64),
+# the largest two-wave size (122), three waves (123 ... 127 = the largest the layout kernels take)
+SHAPES = [(9, 32, 72), (4, 5, 65), (3, 7, 66), (5, 12, 67), (6, 3, 100), (3, 7, 121), (2, 9, 122), (3, 4, 123),
+          (5, 12, 127), (130, 32, 72), (67, 33, 90)]
+
+
+@pytest.fixture(autouse=True)
+def _defaults(mpdata):
+    mpdata.set_wm_flags(0)
+    mpdata.set_plan_layout(mpdata.LAYOUT_WAVEMAJOR)
+    yield
+    mpdata.set_variant(mpdata.VARIANT_EXACT)
+
+
+def _run(M, inp, ntr=1):
+    ncrms, nxp6, nzm = inp["f"].shape[:3]
+    p = M.Plan(ncrms, nxp6 - 6, nzm + 1, ntr)
+    assert p.layout == M.LAYOUT_WAVEMAJOR      # (no fall-back to the reference-layout plan and its k-marching kernel)
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run(); p.sync()
+    f = np.empty_like(inp["f"], order="F"); flux = np.empty_like(inp["flux"], order="F")
+    p.download(f, flux)
+    p.close()
+    return f, flux
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+@pytest.mark.parametrize("dist", [1, 3])
+def test_shapes_above_64_levels(mpdata, oracle, shape, variant, dist):
+    M = mpdata
+    var = M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST
+    M.set_variant(var)
+    inp = oracle.make_inputs(*shape, seed=13, dist=dist)
+    f, flux = _run(M, inp)
+    f_ref, flux_ref = oracle.advect(inp, nthreads=4)
+    nzm = shape[2] - 1
+    if var == M.VARIANT_EXACT:
+        assert np.array_equal(f, f_ref), f"max|df| = {max_abs(f, f_ref):.3e}"
+        assert np.array_equal(flux, flux_ref), f"max|dflux| = {max_abs(flux, flux_ref):.3e}"
+    elif dist == 1:
+        assert max_abs(f, f_ref) < 1e-12 and max_abs(flux, flux_ref) < 1e-12
+    else:
+        assert oracle.rel_l1(f, f_ref) < 1e-14 and oracle.rel_l1(flux[:, :nzm], flux_ref[:, :nzm]) < 1e-14
+    # output contract: columns -2 and nx+3 untouched, flux(:,nz) untouched
+    assert np.array_equal(f[:, 0], inp["f"][:, 0]) and np.array_equal(f[:, -1], inp["f"][:, -1])
+    assert np.array_equal(flux[:, -1], inp["flux"][:, -1])
+
+
+@pytest.mark.parametrize("shape,ntr", [((9, 32, 72), 3), ((21, 7, 100), 2), ((4, 12, 125), 5)])
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_tracer_batches_above_64_levels(mpdata, oracle, shape, ntr, variant):
+    M = mpdata
+    var = M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST
+    M.set_variant(var)
+    base = oracle.make_inputs(*shape, seed=21, dist=3 if var == M.VARIANT_EXACT else 1)
+    fs = [oracle.make_inputs(*shape, seed=210 + t, dist=3 if var == M.VARIANT_EXACT else 1)["f"] for t in range(ntr)]
+    inp = dict(base)
+    inp["f"] = np.asfortranarray(np.stack(fs, axis=-1))
+    inp["flux"] = np.asfortranarray(np.stack([base["flux"]] * ntr, axis=-1))
+    f, flux = _run(M, inp, ntr)
+    for t in range(ntr):
+        f_ref, flux_ref = oracle.advect(dict(base, f=fs[t].copy()), nthreads=4)
+        if var == M.VARIANT_EXACT:
+            assert np.array_equal(f[..., t], f_ref) and np.array_equal(flux[..., t], flux_ref)
+        else:
+            assert max_abs(f[..., t], f_ref) < 1e-12 and max_abs(flux[..., t], flux_ref) < 1e-12
+
+
+def test_exact_with_more_columns_than_the_register_park_holds(mpdata, oracle):
+    """EXACT with nx > 36 at nz > 64: the bit-identical flux has no form there -- the plan falls back to the reference
+    layout (k-marching kernel, bit-identical by construction) instead of delivering another flux."""
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    shape = (5, 40, 70)
+    inp = oracle.make_inputs(*shape, seed=5, dist=3)
+    p = M.Plan(*shape, 1)
+    assert p.layout == M.LAYOUT_REFERENCE
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run(); p.sync()
+    f = np.empty_like(inp["f"], order="F"); flux = np.empty_like(inp["flux"], order="F")
+    p.download(f, flux)
+    p.close()
+    f_ref, flux_ref = oracle.advect(inp, nthreads=4)
+    assert np.array_equal(f, f_ref) and np.array_equal(flux, flux_ref)
+    # FAST has no flux order to keep: wave-major at any nx
+    M.set_variant(M.VARIANT_FAST)
+    p = M.Plan(*shape, 1)
+    assert p.layout == M.LAYOUT_WAVEMAJOR
+    p.close()
+
+
+def test_run_uw_and_device_import_above_64_levels(mpdata, oracle):
+    """device-side import / export and a step on fresh reference-layout velocities (conversion path) of such a plan"""
+    import torch
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    shape = (34, 9, 80)
+    inp = oracle.make_inputs(*shape, seed=3, dist=3)
+    other = oracle.make_inputs(*shape, seed=77, dist=3)
+    d = {k: to_dev(v) for k, v in inp.items()}
+    ou, ow = to_dev(other["u"]), to_dev(other["w"])
+    p = M.Plan(*shape, 1)
+    assert p.layout == M.LAYOUT_WAVEMAJOR
+    p.import_device(d["f"], ou, ow, d["rho"], d["rhow"], d["adz"], d["flux"])
+    p.run_uw(d["u"], d["w"])
+    p.sync()
+    fo, flo = torch.empty_like(d["f"]), torch.empty_like(d["flux"])
+    p.export_device(fo, flo)
+    p.sync(); torch.cuda.synchronize()
+    p.close()
+    f_ref, flux_ref = oracle.advect(inp, nthreads=4)
+    assert np.array_equal(to_host(fo), f_ref) and np.array_equal(to_host(flo), flux_ref)
+
+
+def test_sharded_plan_above_64_levels(mpdata, oracle, monkeypatch):
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    monkeypatch.setenv("MPDATA_MULTI_XFER", "direct")
+    shape = (21, 6, 70)
+    inp = oracle.make_inputs(*shape, seed=8, dist=3)
+    p = M.Plan(*shape, 1, devices=[0, 0])
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run(); p.sync()
+    f = np.empty_like(inp["f"], order="F"); flux = np.empty_like(inp["flux"], order="F")
+    p.download(f, flux)
+    p.close()
+    f_ref, flux_ref = oracle.advect(inp, nthreads=4)
+    assert np.array_equal(f, f_ref) and np.array_equal(flux, flux_ref)
+
+
+def test_4096_instances_of_72_levels_and_its_rate(mpdata, oracle):
+    """4096 x 32 x 72 (the size VERDICT r04 names): EXACT f, flux bitwise against the oracle; FAST within 1e-12; the
+    FAST plan run at 65536 x 32 x 72 reaches >= 0.40 of the HBM roofline (the k-marching fall-back: 0.1-0.2)."""
+    import torch
+    M = mpdata
+    shape = (4096, 32, 72)
+    inp = oracle.make_inputs(*shape, seed=100, dist=1)
+    f_ref, flux_ref = oracle.advect(inp, nthreads=16)
+    M.set_variant(M.VARIANT_EXACT)
+    f, flux = _run(M, inp)
+    assert np.array_equal(f, f_ref) and np.array_equal(flux, flux_ref)
+    M.set_variant(M.VARIANT_FAST)
+    f, flux = _run(M, inp)
+    assert max_abs(f, f_ref) < 1e-12 and max_abs(flux, flux_ref) < 1e-12
+    # rate, resident data, cold field sets
+    ncrms, nx, nz = 32768, 32, 72
+    sh = M.shapes(ncrms, nx, nz, 1)
+    d = {k: torch.empty(sh[k], dtype=torch.float64, device="cuda:0") for k in ("f", "u", "w", "rho", "rhow", "adz", "flux")}
+    for k in d:
+        M.fill_synthetic(d[k], k, 100, 1)
+    plans = []
+    for s_ in range(6):
+        p = M.Plan(ncrms, nx, nz, 1)
+        p.set_stream(); p.set_timing(False)
+        M.fill_synthetic(d["f"], "f", 100 + s_, 1)
+        p.import_device(d["f"], d["u"], d["w"], d["rho"], d["rhow"], d["adz"], d["flux"])
+        plans.append(p)
+    for i in range(12):
+        plans[i % 6].run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(24):
+        plans[i % 6].run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 24
+    for p in plans:
+        p.close()
+    frac = M.algorithmic_bytes(ncrms, nx, nz, 1) / (ms * 1e-3) / 8e12
+    print(f"nz = 72, ncrms = {ncrms}: {ms:.4f} ms per plan run = {frac:.3f} of 8 TB/s")
+    assert frac >= 0.40, (ms, frac)
