@@ -347,7 +347,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   // EXACT with a park array (a.wpark != null): bit-identical flux.  The reference adds the limited vertical fluxes
   // ONE BY ONE onto the finished upwind sum (:545, :624), and the first of them exists 30 columns before that sum is
   // complete: every lane parks its nx limited fluxes in [tracer][tile][column 1..nx][lane] (one 512-byte row per wave
-  // and column step), stores the upwind sum alone as flux, and a finishing kernel (mpdata_capi.hip: flux_finish_kernel)
+  // and column step), stores the upwind sum alone as flux, and a finishing kernel (mpdata_plan.hip: flux_finish_kernel)
   // adds the parked terms in the reference's order.  FAST never parks (its flux is a sum in another order anyway).
   constexpr bool CAN_PARK = !FASTV && NPK == 0;
   constexpr bool REG_PARK = !FASTV && NPK > 0;
@@ -948,7 +948,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
 // The counts are INSTRUCTION counts: a pair fetch of an array issues one DMA instruction for the lanes of
 // the main part and one for the other lanes (hipcc keeps an s_cbranch_execz around each, so an empty lane
 // set would issue none) -- both sets are non-empty because 128 <= mainB <= 384, which plan_create asserts
-// (mpdata_capi.hip).
+// (mpdata_plan.hip).
 // The counted waits only rely on LOADS returning in issue order: "at most as many operations
 // outstanding as DMA instructions were issued after the pair's own".  (Counting the column stores
 // issued in between as well -- vmcnt(10) / vmcnt(5) -- is a race: a store may be acknowledged

@@ -1,4 +1,4 @@
-// mpdata_multi.h -- internal interface between mpdata_capi.hip (the plan API) and
+// mpdata_multi.h -- internal interface between mpdata_plan.hip (the plan API) and
 // mpdata_multi.hip (the multi-GPU orchestration on top of single-device plans).
 #ifndef MPDATA_MULTI_H
 #define MPDATA_MULTI_H
@@ -29,6 +29,6 @@ __attribute__((visibility("hidden"))) void mpdata_multi_stats(const mpdata_multi
 __attribute__((visibility("hidden"))) int mpdata_multi_ngpus(const mpdata_multi* m);
 __attribute__((visibility("hidden"))) struct mpdata_plan* mpdata_multi_sub(const mpdata_multi* m, int g);
 __attribute__((visibility("hidden"))) int mpdata_multi_destroy(mpdata_multi* m);
-// (mpdata_capi.hip) flux of every tracer of a single-device plan := 0, queued on the plan's stream
+// (mpdata_plan.hip) flux of every tracer of a single-device plan := 0, queued on the plan's stream
 __attribute__((visibility("hidden"))) int mpdata_plan_zero_flux_internal(struct mpdata_plan* p);
 #endif

@@ -226,7 +226,7 @@ int scatter_array(mpdata_multi* m, int which, const void* src, bool host_origin,
   M_TRACE("scatter array %d tracer %d transport %d host=%d", which, tracer, (int)xf, (int)host_origin);
   if (host_origin && xf == XFER_DIRECT) {
     // every GPU pulls its own slab over its own PCIe link (the library does not page-lock caller
-    // memory, see mpdata_capi.hip: the runtime stages the strided copies)
+    // memory, see mpdata_hostcall.hip: the runtime stages the strided copies)
     for (int g = 0; g < G; ++g) {
       M_HIP(hipSetDevice(m->dev[g]));
       M_HIP(hipMemcpy2DAsync(m->rb[g], (size_t)m->nloc[g] * eb, (const char*)src + (size_t)m->sl0[g] * eb,

@@ -93,13 +93,21 @@ def test_default_kernels_do_not_spill():
         for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
                              text, flags=re.S):
             name, scratch, occ = m.group(1), int(m.group(2)), int(m.group(3))
+            if "wm_odd_kernel" in name:    # tracer batches with an odd count: two-tracer waves + one one-tracer wave per tile
+                seen += 1
+                assert scratch == 0 and occ >= 2, f"{name}: scratch {scratch}, occupancy {occ}"
             if "xmarch" in name or "wm_kernel" in name:
                 seen += 1
-                # template arguments of the wave-major kernel: <R, LPS, WPB, STREAM, TPW, UWREF, UWCONV>
-                t = re.search(r"wm_kernelI(d|Dv2_f)Li(\d+)ELi(\d+)ELb([01])ELi(\d)ELb([01])ELb([01])EEE", name)
+                # template arguments of the wave-major kernel: <R, LPS, WPB, STREAM, TPW, UWREF, UWCONV, NPK>
+                t = re.search(r"wm_kernelI(d|Dv2_f)Li(\d+)ELi(\d+)ELb([01])ELi(\d)ELb([01])ELb([01])ELi(\d+)EEE", name)
                 assert ("wm_kernel" in name) == (t is not None), name
-                lps, tpw, uwref = (int(t.group(2)), int(t.group(5)), t.group(6) == "1") if t else (0, 1, False)
+                lps, tpw, uwref, npk = (int(t.group(2)), int(t.group(5)), t.group(6) == "1", int(t.group(8))) if t else (0, 1, False, 0)
                 exact = "mpdata_exact" in name
+                if npk:    # EXACT with the register park (nx limited vertical fluxes per lane in registers): 2 waves per SIMD
+                    assert exact and scratch == 0 and occ >= 2, f"{name}: scratch {scratch}, occupancy {occ}"
+                    continue
+                if lps == 128:   # nz > 64: several waves per instance, each a one-instance-per-wave form
+                    lps = 64
                 # (the EXACT build of the u, w-ring kernel with one instance per wave -- LPS = 64, a 16-wave workgroup
                 #  that caps the registers at 128 where its other tilings take 132 -- is the parity variant of
                 #  mpdata_plan_run_uw for nz 33 .. 64, not a timed one: a few spilled registers are accepted there)

@@ -1,5 +1,5 @@
 """The host-array call keeps its streams and chunk buffers per host thread between calls (creating and destroying them
-cost 6.7 ms per call: mpdata_capi.hip HostCtx).  Calls of growing and shrinking size, of several tracer counts and from
+cost 6.7 ms per call: mpdata_hostcall.hip HostCtx).  Calls of growing and shrinking size, of several tracer counts and from
 several threads must each give the oracle's result bit for bit; releasing the buffers, and MPDATA_HOST_CACHE=0, must
 change nothing but the time."""
 import os
