@@ -49,16 +49,20 @@ extern "C" {
                                    expression order: f (every element, halos
                                    included) AND flux(:,1:nzm) are BIT-IDENTICAL
                                    to the reference CPU routine built with
-                                   -ffp-contract=off.  For flux the kernels park
+                                   -ffp-contract=off.  For flux the kernels keep
                                    the nx limited vertical fluxes of every lane
-                                   and a finishing kernel adds them onto the
-                                   finished upwind sum one by one, the
-                                   reference's order :545, :624 (a park array of
-                                   the size of f's interior per tracer: with an
-                                   EXACT plan, or allocated and freed in stream
-                                   order around a device call; a third of the
-                                   EXACT variant's speed).  MPDATA_EXACT_FLUX=sum
-                                   in the environment does without it, and calls
+                                   and add them onto the FINISHED upwind sum one
+                                   by one, the reference's order :545, :624:
+                                   wave-major plans with nx <= 36 in registers
+                                   (no extra memory, no extra kernel); the other
+                                   cases -- nx > 36, mpdata_plan_run_uw, calls on
+                                   reference-layout device arrays -- in a park
+                                   array of the size of f's interior per tracer
+                                   (with the plan, or allocated and freed in
+                                   stream order around a device call) that a
+                                   finishing kernel adds.  MPDATA_EXACT_FLUX=sum
+                                   in the environment does without either
+                                   (=hbm: the park array everywhere), and calls
                                    on arrays of 4 GiB and more never park: flux is
                                    then the sum of the reference's terms in
                                    another order (sum of upwind terms + sum of
@@ -102,11 +106,11 @@ int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers,
  * fixes the kernel variant at creation.
  *
  * Device layout.  The arrays a caller passes are ALWAYS in the reference
- * layout above.  Inside a plan with nz <= 64 (fp64; fp32 with an even ncrms) the library keeps them in
+ * layout above.  Inside a plan with nz <= 127 (fp64; fp32 with an even ncrms and nz <= 64) the library keeps them in
  * its own "wave-major" order -- [tile of 64/LPS adjacent instances][column]
- * [instance][level], LPS = 8/16/32/64 >= nz -- so that every wave streams
- * contiguous memory; upload / download / import / export
- * convert on the device.  Other plans (nz > 64, fp32 with an odd ncrms), MPDATA_PLAN_LAYOUT=
+ * [instance][level], LPS = 8/16/32/64 >= nz (nz > 64: one instance per tile, worked on by several waves) -- so that
+ * every wave streams contiguous memory; upload / download / import / export
+ * convert on the device.  Other plans (nz > 127; EXACT with nz > 64 and nx > 36; fp32 with an odd ncrms or nz > 64), MPDATA_PLAN_LAYOUT=
  * reference or mpdata_set_plan_layout(MPDATA_LAYOUT_REFERENCE) keep the
  * reference layout.  Results do not depend on the layout. */
 #define MPDATA_LAYOUT_REFERENCE 0
