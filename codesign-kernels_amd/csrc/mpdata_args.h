@@ -23,6 +23,8 @@ struct MpdataArgsT {
   unsigned long long* dbg;  // unused by these kernels (the wave-major kernels' diagnostic build has its own: MpdataWmArgsT::dbg)
   R* wpark;                 // x-marching kernels, EXACT only, may be null: park array of the limited vertical fluxes,
                             // [workgroup][column 1..nx][thread] (bit-identical flux: xmarch_flux_finish_kernel adds them in order)
+  int park_regs;            // x-marching kernels, EXACT only: 1 = keep the limited vertical fluxes in registers instead
+                            // (nx <= MPDATA_WM_NPK, arrays below 4 GiB; wpark is then null)
 };
 typedef MpdataArgsT<double> MpdataArgs;
 typedef MpdataArgsT<float> MpdataArgsF32;

@@ -61,11 +61,27 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "mpdata_args.h"
 
 namespace MPDATA_NS {
 namespace v2 {
+
+// Register park of the EXACT kernels (bit-identical flux without a park array): PK[STRIDE * trip + OFF] = v with a
+// compile-time index in every branch of a wave-uniform chain on the trip number, so that the array stays in registers.
+// (The empty asm statement keeps the optimiser from merging the branches' stores into ONE store through a selected
+//  pointer, which would turn the array into scratch memory.)
+template <int IDX, typename R, int N> __device__ __forceinline__ void pk_set(R (&PK)[N], const R v) {
+  if constexpr (IDX >= 0 && IDX < N) {
+    PK[IDX] = v;
+    asm volatile("; park %0" ::"i"(IDX));
+  }
+}
+template <int STRIDE, int OFF, typename R, int N, int... TT>
+__device__ __forceinline__ void pk_put(R (&PK)[N], const int trip, const R v, std::integer_sequence<int, TT...>) {
+  ((trip == TT ? pk_set<STRIDE * TT + OFF>(PK, v) : (void)0), ...);
+}
 
 
 // ---- real-type helpers.  R is the type a LANE computes in:
@@ -322,8 +338,10 @@ __device__ __forceinline__ void xm_block_map(const unsigned L, const unsigned nb
 // NT (fp64, one tracer per launch): row fetches and row stores with the streaming cache policy.
 // Every 128-byte row segment is touched by exactly one fetch and one store instruction, so
 // nothing is lost by not keeping it, and the pair of hints buys 1-3 % (either alone: nothing).
-template <typename R, int LPS, int G, bool BIG, bool NT = false>
-__global__ void __launch_bounds__(G * LPS, (TileV2<R, LPS, G>::MIN_WAVES))
+// NPK > 0 (EXACT, nx <= NPK; round 5): the lane's limited vertical fluxes stay in NPK registers and are added onto the
+// finished upwind sum behind the march, in the reference's order -- no park array, no finishing kernel; 2 waves per SIMD.
+template <typename R, int LPS, int G, bool BIG, bool NT = false, int NPK = 0>
+__global__ void __launch_bounds__(G * LPS, (NPK > 0 ? 2 : TileV2<R, LPS, G>::MIN_WAVES))
 mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   constexpr int LD_AUX = NT ? 2 : 0;
   constexpr int ST_AUX = (NT && std::is_same<R, double>::value) ? 2 : 0;
@@ -488,10 +506,12 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
   // fluxes ([workgroup][column][thread]), flux gets the upwind sum alone, xmarch_flux_finish_kernel adds the rest in order
   // (not in the instantiation for arrays of 4 GiB and more: its per-wave descriptors leave no scalar registers for it)
 #ifdef MPDATA_FAST_DIV
-  constexpr bool CAN_PARK = false;
+  constexpr bool CAN_PARK = false, REG_PARK = false;
 #else
-  constexpr bool CAN_PARK = !BIG;
+  constexpr bool CAN_PARK = !BIG && NPK == 0, REG_PARK = NPK > 0;
 #endif
+  static_assert(NPK % 3 == 0, "register park: whole trips of three columns");
+  [[maybe_unused]] R PK[NPK > 0 ? NPK : 1];   // REG_PARK: limited vertical flux of column i = PK[i - 1] (constant indices only)
   [[maybe_unused]] const bool park = CAN_PARK && a.wpark != nullptr;
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsp =
       make_rsrc(a.wpark + (long long)blockIdx.x * nx * T::THREADS, park ? (long long)nx * T::THREADS * RB : 0);
@@ -660,7 +680,10 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
         const R mxd = DN_C(MXN_2);
         const R mnd = DN_C(MNN_2);
         const R W3 = W2p * dmin(MXN_2, mnd) - W2n * dmin(mxd, MNN_2);  // :623
-        if (CAN_PARK && park) {   // EXACT, bit-identical flux: parked, added behind the launch in the reference's order
+        if constexpr (REG_PARK) {
+          // column i = q - 2 = 3 * trip + PH - 4 (PH = (q + 2) mod 3): a wave-uniform branch on the trip number
+          pk_put<3, PH - 5>(PK, (q + 2 - PH) / 3, W3, std::make_integer_sequence<int, NPK / 3 + 2>{});
+        } else if (CAN_PARK && park) {   // EXACT, bit-identical flux: parked, added behind the launch in the reference's order
           unsigned z;   // (the lane's byte offset from the execution mask: no register carries it through the march)
           asm volatile("s_mov_b32 %0, 0" : "=s"(z));
           const unsigned lo = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)) * (unsigned)RB;
@@ -782,7 +805,13 @@ mpdata_advect_xmarch_kernel(const MpdataArgsT<R> a) {
     }
   }
 
-  if (lvl_ok && slc_ok) flux[sl_c + ncrms * (long long)(k - 1)] = (CAN_PARK && park) ? S1 : S1 + S3;  // :541-547, :624
+  R fl = ((CAN_PARK && park) || REG_PARK) ? S1 : S1 + S3;  // :541-547, :624
+  if constexpr (REG_PARK) {   // ... + www(1) + www(2) + ... + www(nx), one by one (:624)
+#pragma unroll
+    for (int i = 0; i < NPK; ++i)
+      if (i < nx) fl = fl + PK[i];
+  }
+  if (lvl_ok && slc_ok) flux[sl_c + ncrms * (long long)(k - 1)] = fl;
 }
 
 // EXACT, bit-identical flux: flux (the upwind sum, as the kernel above left it) += the nx parked limited vertical

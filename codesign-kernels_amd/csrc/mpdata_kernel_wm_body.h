@@ -191,20 +191,6 @@ struct TileWm {
 // WRITES the u, w values it reads from the workgroup's ring into the plan's own u, w arrays (plan layout: its
 // lane's element of the column, the very offsets f's store uses) -- the first tracer of the batch is advected by
 // this kernel, and the batch kernel behind it finds the converted velocities without a conversion pass.
-// register park (wm_body, NPK > 0): PK[6 * trip + M - 5] = v with a compile-time index in every branch
-// (the empty asm statement keeps the optimiser from merging the branches' stores into ONE store through a selected
-//  pointer, which would turn the array into scratch memory)
-template <int IDX, typename R, int N> __device__ __forceinline__ void pk_set(R (&PK)[N], const R v) {
-  if constexpr (IDX >= 0 && IDX < N) {
-    PK[IDX] = v;
-    asm volatile("; park %0" ::"i"(IDX));
-  }
-}
-template <int M, typename R, int N, int... TT>
-__device__ __forceinline__ void pk_put(R (&PK)[N], const int trip, const R v, std::integer_sequence<int, TT...>) {
-  ((trip == TT ? pk_set<6 * TT + M - 5>(PK, v) : (void)0), ...);
-}
-
 // wm_body: everything one wave does for its (tile, first tracer `tr`) -- the body of the kernels below.  `lds` =
 // the workgroup's LDS, `my` = the wave's own ring inside it (the caller lays the rings out: a launch that mixes
 // the two-tracer and the one-tracer form gives every wave a two-tracer-sized ring).
@@ -890,7 +876,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
           // phase and the column of the pair): a wave-uniform branch on the trip number picks the register
           constexpr int M = (PH * 4 + decltype(h_tag)::value * 3) % 6;
           const int trip = (q + 2 - M) / 6;
-          pk_put<M>(PK, trip, W3, std::make_integer_sequence<int, NPK / 6 + 1>{});
+          v2::pk_put<6, M - 5>(PK, trip, W3, std::make_integer_sequence<int, NPK / 6 + 1>{});
         } else if (CAN_PARK && park) park_st(q - 2, W3);   // (EXACT, bit-identical flux: added behind the march, in order)
         else if constexpr (UWREF || T1X) S1 = S1 + W3;  // one accumulator (two registers that kernel does not have)
         else S3 = S3 + W3;  // :624

@@ -62,6 +62,17 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
   dim3 grid((unsigned)ntracers * groups, 1, 1), block(T::THREADS, 1, 1);  // tracer fastest
   // arrays of 4 GiB or more: the instantiation with per-wave descriptor bases
   const bool big = (double)a.ncrms * (a.nx + 6) * a.nz * (double)sizeof(R) >= 4294967000.0;
+#ifndef MPDATA_FAST_DIV
+  // EXACT, bit-identical flux from registers (workgroups of up to 8 waves: a 16-wave workgroup -- nz 33 .. 64, the
+  // 256-byte-row tiling -- caps a wave at 128 registers; those keep the park array)
+  if constexpr (G * LPS <= 512) {
+    if (!big && b.park_regs && b.nx <= MPDATA_WM_NPK && !b.wpark) {
+      hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, false, false, MPDATA_WM_NPK>), grid, block, 0,
+                         (hipStream_t)stream, b);
+      return;
+    }
+  }
+#endif
   if (big)
     hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, true>), grid, block, 0, (hipStream_t)stream, b);
   else if (std::is_same<R, double>::value && G == 16 && ntracers == 1)   // one tracer: streaming rows (+1..3 %)
@@ -230,7 +241,11 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   a.u_ref = nullptr; a.w_ref = nullptr; a.ncrms = 0; a.dbg = a8.dbg;
   a.wpark = reinterpret_cast<v2::f32x2*>(a8.wpark);
   a.park_regs = a8.park_regs;
-  a.nkw = 1;
+  a.nkw = a8.nkw;
+  if (lps == 128) {
+    launch_wm_ks<v2::f32x2>(a, stream);
+    return true;
+  }
 #define X(LPS_)                                \
   if (lps == LPS_) {                           \
     launch_wm_t<v2::f32x2, LPS_, MPDWM_WPB>(a, stream, flags); \
@@ -348,6 +363,7 @@ bool launch_f32(int id, const MpdataArgsF32& a, int ntracers, void* stream) {
     p.f_tstride = a.f_tstride / 2; p.flux_tstride = a.flux_tstride / 2;
     p.dbg = a.dbg;
     p.wpark = reinterpret_cast<v2::f32x2*>(a.wpark);
+    p.park_regs = a.park_regs;
 #define X(ID, LPS_, G_)                                        \
   if (id == ID) {                                              \
     launch_tile_v2<v2::f32x2, LPS_, G_>(p, ntracers, stream);  \

@@ -267,9 +267,9 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   if (rc) return rc;
   const int var = variant();
   // wave-major: fp64, and fp32 with an even ncrms (two adjacent instances per lane = 8-byte elements)
-  // (nz > 64: fp64; EXACT with the flux in the reference's order needs the register park there: nx <= MPDATA_WM_NPK)
-  const bool ks_ok = nz <= 64 || (eb == 8 && (var != MPDATA_VARIANT_EXACT || !exact_flux_in_order() ||
-                                              (exact_flux_in_regs() && nx <= MPDATA_WM_NPK)));
+  // (nz > 64: EXACT with the flux in the reference's order needs the register park there: nx <= MPDATA_WM_NPK)
+  const bool ks_ok = nz <= 64 || var != MPDATA_VARIANT_EXACT || !exact_flux_in_order() ||
+                     (exact_flux_in_regs() && nx <= MPDATA_WM_NPK);
   const bool wmaj = (eb == 8 || (ncrms & 1) == 0) && wm_lps_for(nz) != 0 && ks_ok &&
                     plan_layout_default() == MPDATA_LAYOUT_WAVEMAJOR && tile_override() < 0;
   MpdataTileInfo t;

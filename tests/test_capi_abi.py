@@ -103,6 +103,10 @@ def test_default_kernels_do_not_spill():
                 assert ("wm_kernel" in name) == (t is not None), name
                 lps, tpw, uwref, npk = (int(t.group(2)), int(t.group(5)), t.group(6) == "1", int(t.group(8))) if t else (0, 1, False, 0)
                 exact = "mpdata_exact" in name
+                x = re.search(r"xmarch_kernelI(d|f|Dv2_f)Li(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)EEE", name)
+                assert ("xmarch_kernel" in name) == (x is not None), name
+                if x:
+                    npk = int(x.group(6))
                 if npk:    # EXACT with the register park (nx limited vertical fluxes per lane in registers): 2 waves per SIMD
                     assert exact and scratch == 0 and occ >= 2, f"{name}: scratch {scratch}, occupancy {occ}"
                     continue

@@ -187,3 +187,31 @@ def test_4096_instances_of_72_levels_and_its_rate(mpdata, oracle):
     frac = M.algorithmic_bytes(ncrms, nx, nz, 1) / (ms * 1e-3) / 8e12
     print(f"nz = 72, ncrms = {ncrms}: {ms:.4f} ms per plan run = {frac:.3f} of 8 TB/s")
     assert frac >= 0.40, (ms, frac)
+
+
+@pytest.mark.parametrize("shape", [(10, 9, 72), (4, 5, 65), (6, 12, 127), (130, 32, 72)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_fp32_plans_above_64_levels(mpdata, oracle, shape, variant):
+    """fp32 plans with an even ncrms (two adjacent instances per lane) at nz > 64: the same several-waves-per-instance form
+    in its `float2` instantiation; EXACT f bit-identical to the fp32 oracle.  (Up to round 4: MPDATA_EUNSUPPORTED.)"""
+    M = mpdata
+    F32 = np.float32
+    var = M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST
+    M.set_variant(var)
+    inp = oracle.make_inputs(*shape, seed=21, dist=1, dtype=F32)
+    f_ref, flux_ref = oracle.advect(inp)
+    p = M.Plan(*shape, 1, dtype=F32)
+    assert p.layout == M.LAYOUT_WAVEMAJOR
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run(); p.sync()
+    f = np.empty_like(inp["f"], order="F"); flux = np.empty_like(inp["flux"], order="F")
+    p.download(f, flux)
+    p.close()
+    nzm = shape[2] - 1
+    if var == M.VARIANT_EXACT:
+        assert np.array_equal(f, f_ref) and np.array_equal(flux, flux_ref)
+    else:
+        assert np.abs(f.astype(np.float64) - f_ref).max() < 1e-5
+        d = np.abs(flux[:, :nzm].astype(np.float64) - flux_ref[:, :nzm])
+        assert np.all(d <= 2e-5 * np.maximum(1.0, np.abs(flux_ref[:, :nzm])))
+    assert np.array_equal(flux[:, nzm], inp["flux"][:, nzm])

@@ -380,3 +380,41 @@ def test_exact_flux_without_the_park_array(oracle):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert res["f"] and res["flux_close"]
+
+
+def test_exact_flux_through_the_park_array_everywhere(oracle):
+    """MPDATA_EXACT_FLUX=hbm (read once per process: a child process): round 4's park array + finishing kernel in place of the
+    register park of round 5 -- the path plans with nx > 36, mpdata_plan_run_uw and 16-wave x-march tilings still take --
+    for a plan run, a tracer batch and a reference-layout device call: f AND flux bit-identical."""
+    import os, subprocess, sys, json
+    code = (
+        "import json, numpy as np, sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import codesign_kernels_amd as M\n"
+        "from oracle import oracle as O\n"
+        "from util import run_hip\n"
+        "O.build_lib(); M.set_variant(M.VARIANT_EXACT)\n"
+        "ok = True\n"
+        "for shape, T in (((130, 31, 28), 1), ((37, 9, 17), 3)):\n"
+        "    base = O.make_inputs(*shape, seed=5, dist=3)\n"
+        "    fs = [O.make_inputs(*shape, seed=50 + t, dist=3)['f'] for t in range(T)]\n"
+        "    inp = dict(base)\n"
+        "    if T > 1:\n"
+        "        inp['f'] = np.asfortranarray(np.stack(fs, axis=-1)); inp['flux'] = np.asfortranarray(np.stack([base['flux']] * T, axis=-1))\n"
+        "    else:\n"
+        "        inp['f'] = fs[0]\n"
+        "    p = M.Plan(*shape, T); p.upload(inp['f'], inp['u'], inp['w'], inp['rho'], inp['rhow'], inp['adz'], inp['flux']); p.run(); p.sync()\n"
+        "    f = np.empty_like(inp['f'], order='F'); fl = np.empty_like(inp['flux'], order='F'); p.download(f, fl); p.close()\n"
+        "    for t in range(T):\n"
+        "        fr, flr = O.advect(dict(base, f=fs[t].copy()), nthreads=2)\n"
+        "        ok &= bool(np.array_equal(f[..., t] if T > 1 else f, fr)) and bool(np.array_equal(fl[..., t] if T > 1 else fl, flr))\n"
+        "    one = dict(base, f=fs[0].copy())\n"
+        "    fd, fld = run_hip(M, one)\n"
+        "    fr, flr = O.advect(one, nthreads=2)\n"
+        "    ok &= bool(np.array_equal(fd, fr)) and bool(np.array_equal(fld, flr))\n"
+        "print('RESULT ' + json.dumps({'ok': ok}))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPDATA_EXACT_FLUX="hbm"), capture_output=True,
+                       text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])["ok"]

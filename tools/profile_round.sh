@@ -8,7 +8,7 @@
 # rocprofv3 rules of this pool: the program itself after `--`; --pmc never together with
 # --kernel-trace/--stats; one counter group per pass.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT

@@ -7,7 +7,7 @@
 #   gpurun_out/<tag>_final/fortran_side_drivers.txt  bwk_driver and nested_hip (second / third kernel)
 #   gpurun_out/prof_<tag>/                      tools/profile_round.sh (rocprofv3 kernel trace + PMC passes)
 # then here: python tools/pmc_summary.py <tag>; copy the records into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/${TAG}_final
 mkdir -p $OUT
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; echo "bench driver rc=$?"
