@@ -256,7 +256,7 @@ int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u,
   a.park_regs = 0;
   void* park_mem = nullptr;
   const bool big = (double)ncrms * (nx + 6) * nz * (double)(t.id >= 40 ? 8 : t.elem_bytes) >= 4294967000.0 * (t.id >= 40 ? 2 : 1);
-  if (var == MPDATA_VARIANT_EXACT && t.nz_max < (1 << 30) && !big && exact_flux_in_regs() && nx <= MPDATA_WM_NPK && t.threads <= 512) {
+  if (var == MPDATA_VARIANT_EXACT && t.nz_max < (1 << 30) && exact_flux_in_regs() && nx <= MPDATA_WM_NPK && t.threads <= 512) {
     a.park_regs = 1;   // (round 5) in registers: no park array, no finishing kernel
   } else if (var == MPDATA_VARIANT_EXACT && t.nz_max < (1 << 30) && !big && exact_flux_in_order()) {
     const size_t groups = (size_t)((ncrms + t.slw - 1) / t.slw);

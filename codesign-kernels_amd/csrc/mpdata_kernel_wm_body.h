@@ -163,7 +163,6 @@ struct TileWm {
   static constexpr int SLOT = UWREF_ ? ARR : (2 + TPW_) * ARR;   // (UWREF: the wave's own ring holds f only)
   static constexpr int LDS_ELEMS = WPB_ * NS * SLOT + (UWREF_ ? NS * XSLOT : 0);
   static_assert(!UWREF_ || (!KS && WPB_ * (64 / LW) == GX && TPW_ == 1), "UWREF: 16 instances per workgroup, one tracer per wave");
-  static_assert(!KS || TPW_ == 1, "nz > 64: one tracer per wave");
   // 128 VGPRs; one instance per wave (LPS = 64) carries the ghost-level select of w and gets 168
   // (two tracers per wave: twice the tracer state, 256 VGPRs, 2 waves per SIMD)
   // UWREF: 16 / SLP waves per workgroup.  FAST fits 128 VGPRs (two workgroups of 8 waves per CU at
@@ -208,7 +207,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   static_assert(NPK == 0 || (TPW == 1 && !UWREF && NPK % 6 == 0), "register park: one tracer per wave, whole trips of six columns");
   constexpr bool KS = T::KS;
   constexpr int LW = T::LW;
-  static_assert(!KS || (!STREAM && TPW == 1 && !UWREF), "nz > 64: the batch form of the data movement (one fetch instruction per array and pair)");
+  static_assert(!KS || (!STREAM && !UWREF), "nz > 64: the batch form of the data movement (one fetch instruction per array and pair)");
   using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
   // T1X (FAST, one tracer per wave; fp64 and the two-instances-per-lane fp32 form): the 7-operation extrema and the ring sums of the two-tracer form
   // (XNEW, XSUM below: 6 operations per column fewer) in 128 VGPRs.  The registers come from: rho folded into

@@ -65,10 +65,16 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
 #ifndef MPDATA_FAST_DIV
   // EXACT, bit-identical flux from registers (workgroups of up to 8 waves: a 16-wave workgroup -- nz 33 .. 64, the
   // 256-byte-row tiling -- caps a wave at 128 registers; those keep the park array)
+  // (arrays of 4 GiB and more: the instantiation with per-wave descriptor bases has no scalar registers for a park
+  //  DESCRIPTOR -- the register park needs none: bit-identical flux there as well since round 5)
   if constexpr (G * LPS <= 512) {
-    if (!big && b.park_regs && b.nx <= MPDATA_WM_NPK && !b.wpark) {
-      hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, false, false, MPDATA_WM_NPK>), grid, block, 0,
-                         (hipStream_t)stream, b);
+    if (b.park_regs && b.nx <= MPDATA_WM_NPK && !b.wpark) {
+      if (big)
+        hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, true, false, MPDATA_WM_NPK>), grid, block, 0,
+                           (hipStream_t)stream, b);
+      else
+        hipLaunchKernelGGL((v2::mpdata_advect_xmarch_kernel<R, LPS, G, false, false, MPDATA_WM_NPK>), grid, block, 0,
+                           (hipStream_t)stream, b);
       return;
     }
   }
@@ -180,6 +186,15 @@ static void launch_wm_ks(const MpdataWmArgsT<R>& a, void* stream) {
 #ifndef MPDATA_FAST_DIV
   if (a.park_regs && a.nx <= MPDATA_WM_NPK) {
     hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 1, false, false, MPDATA_WM_NPK>), dim3(blocks),
+                       dim3(64 * WPB), 0, (hipStream_t)stream, a);
+    return;
+  }
+#endif
+#ifdef MPDATA_FAST_DIV
+  // FAST tracer batches: two tracers per wave here as well (an odd last tracer: a wave with an empty second half)
+  if (a.ntracers >= 2) {
+    const long long per_xcd2 = ((long long)(a.ntiles + 7) / 8) * ((a.ntracers + 1) / 2) * a.nkw;
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 2>), dim3((unsigned)(8 * ((per_xcd2 + WPB - 1) / WPB))),
                        dim3(64 * WPB), 0, (hipStream_t)stream, a);
     return;
   }
