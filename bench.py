@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=500.0,
                     help="CAP of the untimed GPU wake-up before the warm-up steps: scratch launches of the same kernel "
                          "on cold field sets until their time has settled (plateau rule, wake_up()) or this long, so "
-                         "that the clock / power-state ramp after idle (DESIGN.md 5) is over even when --warmup is "
+                         "that the clock / power-state ramp after idle (DESIGN.md 7) is over even when --warmup is "
                          "small; 0 disables")
     ap.add_argument("--prewarm-min-ms", type=float, default=40.0,
                     help="the wake-up lasts at least this long (the first launches after idle run fast, the power "
@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--no-exact", action="store_true", help="skip the exact_variant side block (EXACT: plan run, 25 tracers, device call)")
     ap.add_argument("--aligned", action="store_true",
                     help="allocate f, u, w with equally aligned bases (plain torch.empty) instead of the "
-                         "staggered placement (DESIGN.md 4.4: 8 %% slower at ncrms=65536)")
+                         "staggered placement (DESIGN.md 4.3: 8 %% slower at ncrms=65536)")
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--dist", type=int, default=1, help="1 conditioned, 2 reference-raw, 3 raw-signed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--no-reflayout", action="store_true",
                     help="skip the side measurement of the reference-layout device call (x-march kernel)")
     ap.add_argument("--serpentine", action="store_true",
-                    help="serpentine tile order (DESIGN.md 4.6): off by default, only pays with --shared-uw")
+                    help="serpentine tile order (DESIGN.md 4.1): off by default, only pays with --shared-uw")
     ap.add_argument("--shared-uw", action="store_true",
                     help="headline on ONE plan whose field sets share u, w (round-2 protocol); default: a plan per "
                          "field set with its own u, w")
@@ -455,7 +455,7 @@ def wake_up(torch, prewarm_launch, cap_ms, min_ms):
     """GPU wake-up before the warm-up steps, PLATEAU rule: scratch launches of the block's own kernel on cold field
     sets, in groups of 8 with one HIP-event pair per group, until three consecutive groups agree within 1 % (and at
     least `min_ms` have passed: the first launches after idle run FAST, then the power management takes the clock
-    down, DESIGN.md 5) or `cap_ms` have passed.  A fixed 60 ms (round 4) was over before the clock had settled on a
+    down, DESIGN.md 7) or `cap_ms` have passed.  A fixed 60 ms (round 4) was over before the clock had settled on a
     fresh box: the 20 timed steps of the driver's command (8 ms) then sat on the ramp.  The reference's own protocol
     is the same idea -- the first call pays the warm-up, the second is quoted (results/advect.pgiacc.17.7:2-13)."""
     info = {"rule": "groups of 8 cold launches until 3 consecutive group means agree within 1 %",
@@ -1249,7 +1249,7 @@ def main():
         del host
         return min(ts[1:]), lambda dtm: {
             "workload": f"mpdata_advect_scalar2d on host arrays (pageable), ncrms={n_loc} nx={nx} nz={nz}, 1 tracer: "
-                        "H2D + kernel + D2H, chunked and pipelined (DESIGN.md 5b)",
+                        "H2D + kernel + D2H, chunked and pipelined (DESIGN.md 5)",
             "seconds_first_call": ts[0], "seconds": min(ts[1:]),
             "value": cells_1 / min(ts[1:]), "unit": "cell-updates/s",
             "note": "PCIe-inclusive; reported beside the device-resident `value`, never as it"}

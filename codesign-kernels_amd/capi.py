@@ -228,7 +228,7 @@ def shapes(ncrms, nx, nz, ntracers=1):
             "flux": t + (nz, ncrms)}
 
 
-# Placement advice for callers that own the device arrays (DESIGN.md section 4.4): a
+# Placement advice for callers that own the device arrays (DESIGN.md section 4.3): a
 # workgroup reads the same instance range of f, u and w at about the same time; when the
 # three base addresses are equal modulo 1 KiB those requests meet on the same HBM channel
 # (8 % slower at ncrms = 65536).  The library's own buffers (plans, host-array calls) are

@@ -2,7 +2,7 @@
 // (three arrays read, one written, in place) with the friendliest possible access pattern: every
 // workgroup moves one contiguous, aligned 16-KiB piece of each array with 16-byte loads / stores,
 // all loads issued before the first store.  The arrays hold pseudo-random values (on all-zero
-// data the chip clocks higher and the figure flatters: DESIGN.md section 4.6).  bench.py prints it beside the 8 TB/s specification
+// data the chip clocks higher and the figure flatters: DESIGN.md section 4.1).  bench.py prints it beside the 8 TB/s specification
 // ("also record a measured ... ceiling on the box").  Not on the hot path.
 #include <hip/hip_runtime.h>
 

@@ -6,7 +6,7 @@
 // with the same lane mapping (a LANE owns one (CRM instance, level k) pair, a wave holds
 // SLP = 64/LPS adjacent instances, vertical neighbours by DPP), the same march over the x
 // columns and the same 3-column register pipeline -- but on a device layout that is PRIVATE to a
-// plan (DESIGN.md section 4.6).  The reference layout (sl fastest, :33-38) makes every (column,
+// plan (DESIGN.md section 4.1).  The reference layout (sl fastest, :33-38) makes every (column,
 // level) row of every array its own stream, of which a wave can use 16 bytes; the x-march kernel
 // therefore needs a workgroup of 8 waves, a transposing LDS ring and a barrier per column to
 // read 128-byte row segments.  Here the arrays are stored

@@ -1,5 +1,5 @@
 // Diagnostic microbenchmark: data-movement skeleton of the "wave-major" private layout
-// (DESIGN.md section 4.6): every wave owns SLP adjacent instances and streams its own linear
+// (DESIGN.md section 4.1): every wave owns SLP adjacent instances and streams its own linear
 // image  [tile][column][instance-in-tile][level]  of f, u, w -- no workgroup barrier, no LDS
 // transpose -- through a per-wave LDS-DMA ring, and stores the column back from registers.
 // Variants: 16-B DMA of column PAIRS vs 4-B DMA of single columns, ring depth, waves per
@@ -303,7 +303,7 @@ int main(int argc, char** argv) {
     char *f, *u, *w, *fo;
     (void)hipMalloc(&f, n + 8192); (void)hipMalloc(&u, n + 8192); (void)hipMalloc(&w, n + 8192); (void)hipMalloc(&fo, n + 8192);
     // pseudo-random contents by default (`./wave_stream zero`: all-zero arrays -- the chip then clocks
-    // higher and the rates flatter: DESIGN.md section 4.6)
+    // higher and the rates flatter: DESIGN.md section 4.1)
     if (argc > 1 && argv[1][0] == 'z') {
       (void)hipMemset(f, 0, n); (void)hipMemset(u, 0, n); (void)hipMemset(w, 0, n); (void)hipMemset(fo, 0, n);
     } else {
