@@ -209,6 +209,14 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   constexpr int LW = T::LW;
   static_assert(!KS || (!STREAM && !UWREF), "nz > 64: the batch form of the data movement (one fetch instruction per array and pair)");
   using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
+  // PRE: the LDS inputs of a column step are read one step AHEAD of their use (software pipelining; the pair loop
+  // holds them in registers) -- two tracers per wave: with two waves per SIMD an exposed LDS round trip at the top of
+  // every step is not hidden by other waves.  (The register-park form of EXACT, also two waves per SIMD, was measured
+  // with it in round 5: 0.531 against 0.533 ms, 25 tracers 11.44 against 11.37 -- it is bound by its IEEE divisions,
+  // not by LDS latency; profiles/r05_ab_exact_prefetch.txt.  Left as it was.)
+  constexpr bool PRE = TPW == 2;
+  // DMA instructions one pair fetch issues (what the counted waits count)
+  constexpr int DMA_PER_PAIR = STREAM ? 6 : 2 + TPW;
   // T1X (FAST, one tracer per wave; fp64 and the two-instances-per-lane fp32 form): the 7-operation extrema and the ring sums of the two-tracer form
   // (XNEW, XSUM below: 6 operations per column fewer) in 128 VGPRs.  The registers come from: rho folded into
   // the limiter's reciprocal, one flux accumulator, ONE ring value dW/adz - U per column instead of U and dW
@@ -440,7 +448,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   };
   // store offset of column c = q - 1 of the step about to run; the march starts at q = -2, behind one
   // empty flush of the deferred-store slot, which advances the offset as well
-  unsigned scur = out_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) - (TPW == 1 ? 4u : 3u) * cstride : OOB;
+  unsigned scur = out_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) - (PRE ? 3u : 4u) * cstride : OOB;
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   // pair P of all three arrays into its ring slot.  e*/o*: which columns of the pair exist for
@@ -626,7 +634,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
           __builtin_amdgcn_raw_buffer_store_b64(bw, rsw, (int)ow, (int)((unsigned)max(c, 0) * remB), 0);
         }
       }
-    } else if constexpr (TPW == 1) {
+    } else if constexpr (!PRE) {
       f0q = ldv(p_own + LO);
       uq = p_own[LO + T::UO];
       wq = p_own[LO + T::WO];
@@ -643,7 +651,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
 #define UP_C(x) shift_up_clamped((x), own_up)
 #define UP_G(x) shift_up(x)
     V f0d, f0u;
-    if constexpr (TPW == 1) {
+    if constexpr (!PRE) {
       // (by DPP from f0q instead -- two 32-bit select-moves per value in place of an LDS read, no address registers:
       //  0.3885 against 0.3868 ms interleaved, round 4: the LDS reads are the cheaper form, also under the power cap)
       f0d = ldv(p_dn + LO);
@@ -734,7 +742,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
     if constexpr (UWREF) {
       ud = x_dn[XO];
       wu = x_up[XO + T::XARR];
-    } else if constexpr (TPW == 1) {
+    } else if constexpr (!PRE) {
       ud = p_dn[LO + T::UO];
       wu = p_up[LO + T::WO];
     } else {
@@ -765,7 +773,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
     {
       const bool act = q - 3 >= -1 && q - 3 <= nx + 2;
       const V vs = f1_1 + S.F1[C2] + S.MX0[C2] + S.MN0[C2] + S1 + (G.SU[C1] + G.SW[C0]);
-      if constexpr (decltype(h_tag)::value == (TPW == 1 ? 1 : 0)) {
+      if constexpr (decltype(h_tag)::value == (PRE ? 0 : 1)) {
         v_def = vs; act_def = FULL || act; c_def = max(q - 1, 0);
       } else {
         st_col(FULL || act, max(q - 1, 0), vs, std::integral_constant<int, 0>{});
@@ -894,7 +902,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
       // before it would stall it for a store round trip (+1 % one tracer, +3.5 % tracer batches)
       // (two tracers per wave: the wait sits between the two steps of a pair, and it is the even
       //  column's store that is held back past it)
-      if constexpr (decltype(h_tag)::value == (TPW == 1 ? 1 : 0)) {
+      if constexpr (decltype(h_tag)::value == (PRE ? 0 : 1)) {
         v_def = v; act_def = FULL || act; c_def = max(n + 2, 0);
       } else {
         st_col(FULL || act, max(n + 2, 0), v, std::integral_constant<int, 0>{});
@@ -956,7 +964,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
     step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1, in_e);      \
     asm volatile("" ::: "memory");                      \
     DMA((q) + 1);                                       \
-  } else if constexpr (TPW == 1) {                      \
+  } else if constexpr (!PRE) {                          \
     if constexpr (STREAM) MPDWM_WAIT("s_waitcnt vmcnt(12)") \
     else MPDWM_WAIT("s_waitcnt vmcnt(6)")               \
     MPDWM_FLUSH_DEFERRED                                \
@@ -968,7 +976,9 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   } else {                                              \
     const LdsIn in_o = lds_in(SL{}, I1{});              \
     step(PHA{}, SL{}, I0{}, TAG{}, (q), in_e);          \
-    MPDWM_WAIT("s_waitcnt vmcnt(4)")                    \
+    if constexpr (DMA_PER_PAIR == 4) MPDWM_WAIT("s_waitcnt vmcnt(4)")      \
+    else if constexpr (DMA_PER_PAIR == 3) MPDWM_WAIT("s_waitcnt vmcnt(3)") \
+    else MPDWM_WAIT("s_waitcnt vmcnt(6)")               \
     MPDWM_FLUSH_DEFERRED                                \
     in_e = lds_in(SLN{}, I0{});                         \
     step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1, in_o);      \
@@ -979,8 +989,10 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   // pair, the next pair's in_e in its middle, behind the wait for that pair: the only DMA group
   // issued after it is the one of the pair after next -- 4 instructions).
   LdsIn in_e;
-  if constexpr (TPW == 2) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // pair 0 (pairs 1, 2 were issued after it)
+  if constexpr (PRE) {   // pair 0 (pairs 1, 2 were issued after it: two groups of DMA_PER_PAIR instructions)
+    if constexpr (DMA_PER_PAIR == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (DMA_PER_PAIR == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     in_e = lds_in(I0{}, I0{});
   }
   int q0 = -2;
@@ -997,7 +1009,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   }
   // drain: pairs beyond the last column are not run (+2 % at 25 tracers).  The two forms of the
   // same thing are what the register allocator accepts without spilling in either case.
-  if constexpr (TPW == 2) {
+  if constexpr (PRE) {
     for (; q0 <= q_last; q0 += 6) {
       MPDWM_PAIR(I0, I1, I0, I1, Part, q0, dma_p)
       if (q0 + 2 > q_last) break;
@@ -1024,7 +1036,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
 #undef MPDWM_PAIR
 #undef MPDWM_FLUSH_DEFERRED
 
-  if constexpr (TPW == 1) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
+  if constexpr (!PRE) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
   {  // flux (:541-547, :624)
     V fl = ((UWREF || T1X) || (CAN_PARK && park) || REG_PARK) ? S1 : S1 + S3;   // (parked: the upwind sum alone)
     if constexpr (REG_PARK) {   // ... + www(1) + www(2) + ... + www(nx), one by one (:624)

@@ -36,5 +36,7 @@ def test_live_line_meets_the_contract():
     for blk in ("step_with_fresh_uw", "twice_the_instances", "tracer_batched", "reference_layout_device_call",
                 "exact_variant"):
         assert d[blk]["value"] > 0 and 0 < d[blk]["roofline"]["frac"] < 1, blk
+    tf = d["two_launches_in_flight"]   # throughput only: no per-kernel duration is claimed when two kernels share the chip
+    assert tf["value"] > 0 and "roofline" not in tf and 0 < tf["frac_of_8TBs_throughput"] < 1
     ex = d["exact_variant"]     # the variant a default caller gets has a number of its own: plan run, batch, device call
     assert ex["tracer_batched"]["value"] > 0 and ex["reference_layout_device_call"]["value"] > 0
