@@ -543,6 +543,23 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   for (int j = 0; j < T::NS * T::SLOT / 64; ++j) my[j * 64 + lane] = R(0.25) + R(0.001) * R((j * 64 + lane) % 97) - R(0.3) * R(lane & 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
+#ifdef MPDWM_EXECMASK
+  // EXPERIMENT (round 5): lanes that own neither a level (k <= nz, the ghost level included) nor a 16-byte piece of a
+  // column fetch are switched OFF for the whole march (nz = 28: 8 of 64 lanes) -- the kernel runs at the power cap, and
+  // a lane that computes on zeros still draws.  The zero tails of the LDS blocks, which those lanes' fetches used to
+  // rewrite with every pair, are written once here instead.  DPP reads of a disabled lane deliver 0 (bound_ctrl).
+  if constexpr (!UWREF && !KS) {
+#pragma unroll
+    for (int j = 0; j < T::NS * T::SLOT / T::ARR; ++j) {
+      my[j * T::ARR + 2 * lane] = R(0);
+      my[j * T::ARR + 2 * lane + 1] = R(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const bool keep = (lane % LW) < nz || (unsigned)((lane & 31) * 16) < chunkB;
+    const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+    asm volatile("s_mov_b64 exec, %0" ::"s"(km) : "memory");
+  }
+#endif
 #pragma unroll
   for (int P = 0; P < T::NS; ++P) {
     st_col(false, 0, V(R(0)), std::integral_constant<int, 1>{});

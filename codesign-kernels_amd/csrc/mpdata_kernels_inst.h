@@ -295,6 +295,9 @@ const char* build_flags() {
 #ifdef MPDWM_STAMPS
          " MPDWM_STAMPS"
 #endif
+#ifdef MPDWM_EXECMASK
+         " MPDWM_EXECMASK"
+#endif
       ;
 }
 

@@ -19,6 +19,8 @@ K_WMO = "mpdata_advect_wm_odd_kernel<double,32,4"           # round 5: tracer ba
 def is_k(kernel, name):
     """kernel-name match on the demangled name, blanks ignored (mangled fragments also accepted)"""
     n = name.replace(" ", "")
+    if "mpdata_exact" in n or "12mpdata_exact" in n:   # (bench.py's exact_variant block launches the EXACT instantiations of the
+        return False                                   #  same templates: the records are the FAST kernels')
     alt = {K_WM1: "wm_kernelIdLi32ELi4ELb1", K_WMT: "wm_kernelIdLi32ELi4ELb0", K_WMX: "wm_kernelIdLi32ELi8ELb1ELi1ELb1",
            K_WMO: "wm_odd_kernelIdLi32ELi4E"}.get(kernel, kernel)
     return kernel in n or alt in n

@@ -16,12 +16,12 @@ cd /tmp && export TMPDIR=/tmp
 # every pass runs ONLY the block whose kernel it profiles (the side blocks launch kernels of the same
 # name at other sizes -- the chunked host call did, round 2 -- and tools/pmc_summary.py additionally keeps
 # only the full-size dispatches of a kernel)
-X="--no-cpu-baseline --no-fp32 --no-bwk --no-reflayout --no-host-call --no-shared-block --no-fresh-uw --no-x2"
+X="--no-cpu-baseline --no-fp32 --no-bwk --no-exact --no-reflayout --no-host-call --no-shared-block --no-fresh-uw --no-x2"
 B="python3 $ROOT/bench.py --steps 20 --warmup 5 $X --no-batched"
 S="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 $X --no-batched"
 T="python3 $ROOT/bench.py --steps 2 --warmup 1 --prewarm-ms 0 --batched-steps 2 $X"
-R="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-fp32 --no-bwk --no-batched --no-host-call --no-shared-block --no-fresh-uw --no-x2"
-U="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-fp32 --no-bwk --no-batched --no-host-call --no-shared-block --no-reflayout"
+R="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-fp32 --no-bwk --no-exact --no-batched --no-host-call --no-shared-block --no-fresh-uw --no-x2"
+U="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-fp32 --no-bwk --no-exact --no-batched --no-host-call --no-shared-block --no-reflayout"
 N="python3 $ROOT/tools/nlk_bench.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o run -- $B > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- $S > $OUT/fetch.log 2>&1
@@ -37,7 +37,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAI
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/ref_fetch -o run -- $R > $OUT/ref_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/ref_write -o run -- $R > $OUT/ref_write.log 2>&1
 # mpdata_plan_run_uw (u, w from the reference layout): kernel trace of the steady block, HBM traffic
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/uw_kt -o run -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --no-bwk --no-batched --no-host-call --no-shared-block --no-reflayout > $OUT/uw_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/uw_kt -o run -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --no-bwk --no-exact --no-batched --no-host-call --no-shared-block --no-reflayout > $OUT/uw_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/uw_fetch -o run -- $U > $OUT/uw_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/uw_write -o run -- $U > $OUT/uw_write.log 2>&1
 # third kernel (high-order flux nest) on the 32 x mesh, local and random connectivity: kernel trace + HBM traffic
