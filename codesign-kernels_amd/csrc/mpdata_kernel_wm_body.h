@@ -332,11 +332,13 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   const unsigned mainB = chunkB / 128u * 128u, remB = chunkB - mainB;
   const unsigned remBase = (unsigned)ncol * mainB;
   const long long tileB = (long long)ncol * chunkB;
-  const __amdgpu_buffer_rsrc_t rsf = v2::make_rsrc(f, (UWREF && !tile_ok) ? 0 : tileB);
-  const __amdgpu_buffer_rsrc_t rsf1 = v2::make_rsrc(f1, has1 ? tileB : 0);
+  // (!tile_ok -- the u, w-ring form and the nz > 64 form, whose workgroups synchronise: a wave beyond the last tile stays
+  //  and works on EMPTY ranges: its fetches deliver zeros, its stores are dropped)
+  const __amdgpu_buffer_rsrc_t rsf = v2::make_rsrc(f, !tile_ok ? 0 : tileB);
+  const __amdgpu_buffer_rsrc_t rsf1 = v2::make_rsrc(f1, (has1 && tile_ok) ? tileB : 0);
   // (UWREF: u, w of the plan are not read; UWCONV writes them)
-  const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : tileB);
-  const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : tileB);
+  const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : (tile_ok ? tileB : 0));
+  const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : (tile_ok ? tileB : 0));
   // EXACT with a park array (a.wpark != null): bit-identical flux.  The reference adds the limited vertical fluxes
   // ONE BY ONE onto the finished upwind sum (:545, :624), and the first of them exists 30 columns before that sum is
   // complete: every lane parks its nx limited fluxes in [tracer][tile][column 1..nx][lane] (one 512-byte row per wave
@@ -533,30 +535,37 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   };
 
   // ---- prologue: pairs 0, 1, 2 into flight, each behind two dropped column stores so that the
-  //      counted wait of the first pairs sees the steady-state op pattern.  The ring needs no
-  //      initialisation: every fetch instruction group writes all 64 x 16 bytes of its array block
-  //      -- a lane that is out of range (the tail of a column block behind the chunk, a column
-  //      that does not exist for u or w) writes zeros --, so the tails that supply f = u = w = 0 of
-  //      the ghost level are (re)written with every pair.
+  //      counted wait of the first pairs sees the steady-state op pattern.  A fetch instruction
+  //      group writes the 16 bytes of every ACTIVE lane of its array block -- a lane that is out of range
+  //      (a column that does not exist for u or w) writes zeros --; the tails of the blocks behind the
+  //      chunk belong to lanes that are switched off below and are zeroed once (u, w-ring form: all
+  //      lanes stay on and rewrite them with every pair).
 #ifdef MPDWM_ABL_NODMA  // timing ablation: arithmetic on (non-zero, finite) stand-in data
 #pragma unroll
   for (int j = 0; j < T::NS * T::SLOT / 64; ++j) my[j * 64 + lane] = R(0.25) + R(0.001) * R((j * 64 + lane) % 97) - R(0.3) * R(lane & 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-#ifdef MPDWM_EXECMASK
-  // EXPERIMENT (round 5): lanes that own neither a level (k <= nz, the ghost level included) nor a 16-byte piece of a
-  // column fetch are switched OFF for the whole march (nz = 28: 8 of 64 lanes) -- the kernel runs at the power cap, and
-  // a lane that computes on zeros still draws.  The zero tails of the LDS blocks, which those lanes' fetches used to
-  // rewrite with every pair, are written once here instead.  DPP reads of a disabled lane deliver 0 (bound_ctrl).
-  if constexpr (!UWREF && !KS) {
+  // Lanes that own neither a real level (k <= nzm) nor a 16-byte piece of a column fetch are switched OFF for the whole
+  // march (nz = 28: 10 of 64 lanes): the kernel runs at the socket's power cap, and a lane that computes on zeros still
+  // draws (round 5: -0.8 % one tracer and 25 tracers, interleaved; profiles/r05_ab_exec_mask.txt).  That includes the
+  // ghost level k = nz: a DPP read of a disabled lane delivers +0 (bound_ctrl), which IS www(:,:,:,nz) = 0 (:511) for
+  // the upward shifts of the level below (W1, W3; its other two upward reads are clamped to itself, :602).  The zero tails
+  // of the LDS blocks, which those lanes' fetches would rewrite with every pair, are written once here instead.
+  // (Not the u, w-ring form: all 64 lanes of its waves fetch rows for the whole workgroup.  Switching them back on for
+  //  those two instructions was built: -0.6 % on mpdata_plan_run_uw -- and wrong at the edges, because every per-lane
+  //  value the re-enabled lanes need must have been formed BEFORE the mask and must never be copied under it; a mask
+  //  that is never lifted has no such lane.)
+#ifndef MPDWM_NO_EXECMASK
+  if constexpr (!UWREF) {
+#ifndef MPDWM_ABL_NODMA   // (that ablation computes on the stand-in data it has just written)
 #pragma unroll
     for (int j = 0; j < T::NS * T::SLOT / T::ARR; ++j) {
       my[j * T::ARR + 2 * lane] = R(0);
       my[j * T::ARR + 2 * lane + 1] = R(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const bool keep = (lane % LW) < nz || (unsigned)((lane & 31) * 16) < chunkB;
-    const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+#endif
+    const unsigned long long km = __builtin_amdgcn_ballot_w64(lvl_ok || in_col < chunkB);
     asm volatile("s_mov_b64 exec, %0" ::"s"(km) : "memory");
   }
 #endif
@@ -965,6 +974,16 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
 // before an older load has landed, and the count then drops below the mark with a DMA of the
 // pair still in flight; seen as sporadic wrong columns with default-policy stores.)
 #define MPDWM_FLUSH_DEFERRED st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
+// nz > 64: the waves of an instance read each other's OUTPUT levels as the halo levels of their own windows, and f is
+// updated in place -- a wave may store a column only when its siblings have FETCHED it.  The waves of an instance
+// are one workgroup; the barrier behind the counted wait of a pair says "everybody's fetch of this pair has landed",
+// and every store issued up to the next barrier is of a column at least one pair older.  (Found in round 5 when
+// 4096 x 32 x 72 failed under load: with 130 instances the siblings had stayed within a pair of each other by luck.)
+#define MPDWM_KS_BARRIER                  \
+  if constexpr (KS) {                     \
+    __builtin_amdgcn_s_barrier();         \
+    asm volatile("" ::: "memory");        \
+  }
 #define MPDWM_PAIR(PHA, PHB, SL, SLN, TAG, q, DMA)      \
   if constexpr (UWREF) {                                \
     /* own f and own share of u, w of this pair have landed (newer loads: f, uw of the next  \
@@ -984,6 +1003,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   } else if constexpr (!PRE) {                          \
     if constexpr (STREAM) MPDWM_WAIT("s_waitcnt vmcnt(12)") \
     else MPDWM_WAIT("s_waitcnt vmcnt(6)")               \
+    MPDWM_KS_BARRIER                                    \
     MPDWM_FLUSH_DEFERRED                                \
     step(PHA{}, SL{}, I0{}, TAG{}, (q), in_e);          \
     asm volatile("" ::: "memory");                      \
@@ -996,6 +1016,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
     if constexpr (DMA_PER_PAIR == 4) MPDWM_WAIT("s_waitcnt vmcnt(4)")      \
     else if constexpr (DMA_PER_PAIR == 3) MPDWM_WAIT("s_waitcnt vmcnt(3)") \
     else MPDWM_WAIT("s_waitcnt vmcnt(6)")               \
+    MPDWM_KS_BARRIER                                    \
     MPDWM_FLUSH_DEFERRED                                \
     in_e = lds_in(SLN{}, I0{});                         \
     step(PHB{}, SL{}, I1{}, TAG{}, (q) + 1, in_o);      \
@@ -1052,6 +1073,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   }
 #undef MPDWM_PAIR
 #undef MPDWM_FLUSH_DEFERRED
+#undef MPDWM_KS_BARRIER
 
   if constexpr (!PRE) st_col(act_def, c_def, v_def, std::integral_constant<int, 0>{});
   {  // flux (:541-547, :624)
@@ -1073,7 +1095,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
     }
     if (okf && tile_ok) flux[posf] = first(fl);
     if constexpr (TPW == 2)
-      if (out_ok && has1) flux1[pos] = second(fl);
+      if (out_ok && has1 && tile_ok) flux1[pos] = second(fl);
   }
 #ifdef MPDWM_STAMPS
   if (a.dbg) {
@@ -1123,15 +1145,37 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
   const unsigned ntr = (unsigned)a.ntracers;
   unsigned tile, tr;
   int kwave = 0;
-  if constexpr (T::KS) wm_wave_to_tile<WPB, TPW>(ntr, wave, tile, tr, (unsigned)a.nkw, &kwave);
-  else wm_wave_to_tile<WPB, TPW>(ntr, wave, tile, tr);
+  if constexpr (T::KS) {
+    // a workgroup = the nkw waves of each of its ipw = max(1, WPB / nkw) instances (they synchronise: MPDWM_KS_BARRIER);
+    // launched with 64 * ipw * nkw threads.  Batches: the workgroups an XCD receives walk through the tracer slots of
+    // one group of ipw instances after the other (u, w of the group stay in that XCD's L2)
+    const unsigned nkw = (unsigned)a.nkw, ipw = WPB / nkw > 0 ? WPB / nkw : 1u;
+    const unsigned ngrp = ((unsigned)a.ntiles + ipw - 1) / ipw;
+    kwave = (int)((unsigned)wave % nkw);
+    unsigned grp;
+    if (ntr == 1 && TPW == 1) {
+      grp = blockIdx.x;
+      tr = 0;
+    } else {
+      const unsigned nxcd = 8, ntw = (ntr + TPW - 1) / TPW;
+      const unsigned v = blockIdx.x / nxcd;
+      tr = (v % ntw) * TPW;
+      grp = (v / ntw) * nxcd + blockIdx.x % nxcd;
+    }
+    if (grp >= ngrp) return;   // (the whole workgroup: before any barrier)
+    tile = grp * ipw + (unsigned)wave / nkw;
+  } else {
+    wm_wave_to_tile<WPB, TPW>(ntr, wave, tile, tr);
+  }
   // UWREF: the waves of a workgroup share the u, w ring (barriers, a share of the row fetches each):
   // a wave beyond the last tile stays, works on an EMPTY f range (fetches deliver zeros, stores are
   // dropped) and reads the constants of the last tile
   bool tile_ok = true;
-  if constexpr (UWREF) {
+  if constexpr (UWREF || T::KS) {
     tile_ok = tile < (unsigned)a.ntiles;
     if (!tile_ok) tile = (unsigned)a.ntiles - 1u;
+    if constexpr (T::KS)
+      if (a.reverse && tile_ok) tile = (unsigned)a.ntiles - 1u - tile;
   } else {
     if (tile >= (unsigned)a.ntiles) return;  // (no barrier anywhere below)
     // serpentine: every other run of a plan walks the tiles from the other end, so that it starts

@@ -176,30 +176,30 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
 template <typename R>
 static void launch_wm_ks(const MpdataWmArgsT<R>& a, void* stream) {
   constexpr int WPB = MPDWM_WPB;
-  unsigned blocks;
-  if (a.ntracers == 1) {
-    blocks = (unsigned)(((long long)a.ntiles * a.nkw + WPB - 1) / WPB);
-  } else {
-    const long long per_xcd = ((long long)(a.ntiles + 7) / 8) * a.ntracers * a.nkw;  // waves of one XCD
-    blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
-  }
+  // a workgroup = the nkw waves of each of its ipw instances (they synchronise once per column pair, see the kernel)
+  const int ipw = WPB / a.nkw > 0 ? WPB / a.nkw : 1;
+  const unsigned threads = 64u * (unsigned)(ipw * a.nkw);
+  const long long ngrp = ((long long)a.ntiles + ipw - 1) / ipw;
+  auto blocks_for = [&](const int slots) -> unsigned {   // slots: tracer slots (waves per instance window) of the launch
+    if (slots == 1) return (unsigned)ngrp;
+    return (unsigned)(8 * ((ngrp + 7) / 8) * slots);
+  };
 #ifndef MPDATA_FAST_DIV
   if (a.park_regs && a.nx <= MPDATA_WM_NPK) {
-    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 1, false, false, MPDATA_WM_NPK>), dim3(blocks),
-                       dim3(64 * WPB), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 1, false, false, MPDATA_WM_NPK>),
+                       dim3(blocks_for(a.ntracers)), dim3(threads), 0, (hipStream_t)stream, a);
     return;
   }
 #endif
 #ifdef MPDATA_FAST_DIV
   // FAST tracer batches: two tracers per wave here as well (an odd last tracer: a wave with an empty second half)
   if (a.ntracers >= 2) {
-    const long long per_xcd2 = ((long long)(a.ntiles + 7) / 8) * ((a.ntracers + 1) / 2) * a.nkw;
-    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 2>), dim3((unsigned)(8 * ((per_xcd2 + WPB - 1) / WPB))),
-                       dim3(64 * WPB), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 2>), dim3(blocks_for((a.ntracers + 1) / 2)),
+                       dim3(threads), 0, (hipStream_t)stream, a);
     return;
   }
 #endif
-  hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 1>), dim3(blocks), dim3(64 * WPB), 0,
+  hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 1>), dim3(blocks_for(a.ntracers)), dim3(threads), 0,
                      (hipStream_t)stream, a);
 }
 bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags) {
@@ -295,8 +295,8 @@ const char* build_flags() {
 #ifdef MPDWM_STAMPS
          " MPDWM_STAMPS"
 #endif
-#ifdef MPDWM_EXECMASK
-         " MPDWM_EXECMASK"
+#ifdef MPDWM_NO_EXECMASK
+         " MPDWM_NO_EXECMASK"
 #endif
       ;
 }

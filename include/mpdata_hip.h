@@ -53,18 +53,19 @@ extern "C" {
                                    the nx limited vertical fluxes of every lane
                                    and add them onto the FINISHED upwind sum one
                                    by one, the reference's order :545, :624:
-                                   wave-major plans with nx <= 36 in registers
-                                   (no extra memory, no extra kernel); the other
-                                   cases -- nx > 36, mpdata_plan_run_uw, calls on
-                                   reference-layout device arrays -- in a park
+                                   at nx <= 36 in registers (plans, and device
+                                   calls with nz <= 32: no extra memory, no extra
+                                   kernel); the other cases -- nx > 36,
+                                   mpdata_plan_run_uw, device calls with nz 33 ..
+                                   64 -- in a park
                                    array of the size of f's interior per tracer
                                    (with the plan, or allocated and freed in
                                    stream order around a device call) that a
                                    finishing kernel adds.  MPDATA_EXACT_FLUX=sum
                                    in the environment does without either
-                                   (=hbm: the park array everywhere), and calls
-                                   on arrays of 4 GiB and more never park: flux is
-                                   then the sum of the reference's terms in
+                                   (=hbm: the park array everywhere; device calls
+                                   on arrays of 4 GiB and more then do not park):
+                                   flux is then the sum of the reference's terms in
                                    another order (sum of upwind terms + sum of
                                    limited terms, each in the reference's i
                                    order), equal to <= 1e-13 relative. */
