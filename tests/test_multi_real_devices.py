@@ -34,7 +34,11 @@ def _ndev():
         return 0
 
 
-def _child(case, sync_each, timeout=900):
+_HUNG = []   # a child that had to be killed at its timeout: the remaining real-device cases of this session are skipped
+             # (a node on which transfers hang would otherwise hold the test run for timeout x cases x 2)
+
+
+def _child(case, sync_each, timeout=300):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("MPDATA_MULTI_SYNC", None)
     env.pop("MPDATA_MULTI_DEVICES", None)
@@ -44,6 +48,7 @@ def _child(case, sync_each, timeout=900):
         r = subprocess.run([sys.executable, RUNNER, json.dumps(case)], env=env, capture_output=True, text=True,
                            timeout=timeout)
     except subprocess.TimeoutExpired as exc:
+        _HUNG.append(case)
         return {"ok": False, "error": f"timeout after {timeout} s (a hang)", "stderr": str(exc.stderr or "")[-1500:]}
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
     if r.returncode != 0 or not lines:
@@ -65,11 +70,13 @@ def run_case(case):
     """default ordering first; on failure ONE retry in a fresh process with MPDATA_MULTI_SYNC=1.
     Returns the result of the mode that passed; fails the test with both reports otherwise -- and also when only
     the fallback passed (the default ordering is what ships)."""
+    if _HUNG:
+        pytest.skip("an earlier real-device case of this session hung (%s): not trying further ones" % json.dumps(_HUNG[0]))
     res = _child(case, False)
     if res.get("ok"):
         _record(case, {"mode_passed": "queued (default)", "result": res})
         return res
-    res2 = _child(case, True)
+    res2 = _child(case, True) if len(_HUNG) < 2 else {"ok": False, "error": "not retried: two cases hung already"}
     _record(case, {"mode_passed": "MPDATA_MULTI_SYNC=1" if res2.get("ok") else None, "default": res, "sync": res2})
     if res2.get("ok"):
         pytest.fail("the DEFAULT (queued) ordering failed on real devices, MPDATA_MULTI_SYNC=1 passed: "
@@ -154,6 +161,8 @@ def test_fortran_driver_device_mode_on_real_devices(oracle, ntr, ngpus):
     import re
     exe = os.path.join(ROOT, "codesign-kernels_amd", "fortran", "advect")
     assert os.path.exists(exe), "Fortran driver not built"
+    if _HUNG:
+        pytest.skip("an earlier real-device case of this session hung")
     ngpus = ngpus or _ndev()
     ncrms, nx, nz, dist = 96 * ngpus + 1, 32, 28, 1
     inp = oracle.make_inputs(ncrms, nx, nz, seed=100, dist=dist, ntracers=ntr)
@@ -167,8 +176,10 @@ def test_fortran_driver_device_mode_on_real_devices(oracle, ntr, ngpus):
             env["MPDATA_MULTI_SYNC"] = "1"
         try:
             res = subprocess.run([exe, str(ncrms), str(nx), str(nz), str(dist), "0", "-", "-", str(ntr), str(ngpus),
-                                  "device"], capture_output=True, text=True, timeout=600, env=env)
+                                  "device"], capture_output=True, text=True, timeout=300, env=env)
         except subprocess.TimeoutExpired:
+            _HUNG.append({"fortran_driver": True, "ngpus": ngpus, "sync_each": sync_each})
+            out = "timeout (a hang)"
             continue
         if res.returncode != 0:
             out = res.stdout + res.stderr
@@ -191,13 +202,15 @@ def test_fortran_driver_device_mode_on_real_devices(oracle, ntr, ngpus):
 @pytest.mark.gpu
 def test_bench_on_two_real_gpus_with_the_plain_command():
     """`python3 bench.py --gpus 2 ...` (no launcher, no rehearsal mode): two ranks over RCCL on two devices"""
+    if _HUNG:
+        pytest.skip("an earlier real-device case of this session hung")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MPDATA_BENCH_REHEARSAL"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
                           "--ncrms-per-gpu", "16384", "--batched-tracers", "3", "--batched-steps", "2", "--no-fp32",
-                          "--no-bwk", "--no-x2", "--no-shared-block", "--no-exact"],
-                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                          "--no-bwk", "--no-x2", "--no-shared-block", "--no-exact", "--block-timeout", "120"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
