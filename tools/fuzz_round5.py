@@ -97,5 +97,66 @@ for it in range(n):
             print("BAD fp32 plan", shape, "layout", lay32, flush=True)
     if (it + 1) % 25 == 0:
         print(f"{it + 1} / {n} cases, {bad} bad", flush=True)
-print(f"fuzz_round5: {n} cases, {bad} bad")
+# ---- second part: tracer subsets (mpdata_plan_run_tracers), the serpentine tile order, run_uw on fresh velocities and
+#      sharded plans (blocks on one device) over the same shape space, EXACT bitwise
+M.set_variant(M.VARIANT_EXACT)
+from util import to_dev, to_host
+for it in range(n // 2):
+    shape = rshape(127)
+    T = int(rng.integers(2, 6))
+    base = O.make_inputs(*shape, seed=17000 + it, dist=3)
+    fs = [O.make_inputs(*shape, seed=18000 + 10 * it + t, dist=3)["f"] for t in range(T)]
+    inp = dict(base, f=np.asfortranarray(np.stack(fs, axis=-1)), flux=np.asfortranarray(np.stack([base["flux"]] * T, axis=-1)))
+    first = int(rng.integers(0, T)); count = int(rng.integers(1, T - first + 1))
+    serp = bool(rng.integers(0, 2))
+    M.set_serpentine(1 if serp else 0)
+    kind = it % 3
+    ok = True
+    try:
+        if kind == 0:      # subset of the tracers, twice (serpentine: the second run walks the tiles from the other end)
+            p = M.Plan(*shape, T)
+            p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+            p.run(first, count); p.sync()
+            f = np.empty_like(inp["f"], order="F"); fl = np.empty_like(inp["flux"], order="F")
+            p.download(f, fl); p.close()
+            for t in range(T):
+                if first <= t < first + count:
+                    fr, flr = O.advect(dict(base, f=fs[t].copy()), nthreads=4)
+                    ok &= bool(np.array_equal(f[..., t], fr)) and bool(np.array_equal(fl[..., t], flr))
+                else:
+                    ok &= bool(np.array_equal(f[..., t], fs[t]))
+        elif kind == 1:    # a step on fresh reference-layout velocities (the plan holds OTHER ones)
+            other = O.make_inputs(*shape, seed=19000 + it, dist=3)
+            d = {k: to_dev(v) for k, v in inp.items()}
+            ou, ow = to_dev(other["u"]), to_dev(other["w"])
+            p = M.Plan(*shape, T)
+            p.import_device(d["f"], ou, ow, d["rho"], d["rhow"], d["adz"], d["flux"])
+            p.run_uw(d["u"], d["w"]); p.sync()
+            fo, flo = torch.empty_like(d["f"]), torch.empty_like(d["flux"])
+            p.export_device(fo, flo); p.sync(); torch.cuda.synchronize(); p.close()
+            f, fl = to_host(fo), to_host(flo)
+            for t in range(T):
+                fr, flr = O.advect(dict(base, f=fs[t].copy()), nthreads=4)
+                ok &= bool(np.array_equal(f[..., t], fr)) and bool(np.array_equal(fl[..., t], flr))
+        else:              # the problem cut into 2-3 blocks on one device
+            if shape[0] >= 3:
+                os.environ["MPDATA_MULTI_XFER"] = "direct" if it % 2 else "p2p"
+                p = M.Plan(*shape, T, devices=[0] * int(rng.integers(2, 4)))
+                p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+                p.run(); p.sync()
+                f = np.empty_like(inp["f"], order="F"); fl = np.empty_like(inp["flux"], order="F")
+                p.download(f, fl); p.close()
+                for t in range(T):
+                    fr, flr = O.advect(dict(base, f=fs[t].copy()), nthreads=4)
+                    ok &= bool(np.array_equal(f[..., t], fr)) and bool(np.array_equal(fl[..., t], flr))
+    except M.MpdataError as exc:
+        ok = False
+        print("ERROR", exc, flush=True)
+    if not ok:
+        bad += 1
+        print("BAD part 2", shape, "T", T, "kind", kind, "first", first, "count", count, "serpentine", serp, flush=True)
+    if (it + 1) % 25 == 0:
+        print(f"part 2: {it + 1} / {n // 2} cases, {bad} bad", flush=True)
+M.set_serpentine(0)
+print(f"fuzz_round5: {n} + {n // 2} cases, {bad} bad")
 sys.exit(1 if bad else 0)
