@@ -58,7 +58,9 @@ struct MpdataWmArgsT {
                            // wave; wpark is then null: no park array, no finishing kernel)
 };
 typedef MpdataWmArgsT<double> MpdataWmArgs;
-#define MPDATA_WM_NPK 36   // columns the register park of the EXACT wave-major kernels holds (six trips of six columns)
+#define MPDATA_WM_NPK 36   // columns the register park of the EXACT kernels holds (six trips of six columns)
+#define MPDATA_WM_NPK2 66  // ... of the second instantiation of the wave-major kernels (nx 37 .. 66: 247 VGPRs, no spill; the
+                           // x-march kernels spill at that size and keep the park array)
 // test switches of the wave-major launch (mpdata_set_wm_flags; MPDATA_WM_NOSTREAM / _TPW1 / _NOSPLIT)
 #define MPDATA_WMF_NOSTREAM 1   // run the batch form of the kernel on a single tracer as well
 #define MPDATA_WMF_TPW1 2       // tracer batches: one tracer per wave

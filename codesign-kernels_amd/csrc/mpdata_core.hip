@@ -231,6 +231,56 @@ bool exact_flux_in_regs() {
   static const bool hbm = getenv("MPDATA_EXACT_FLUX") && !strcmp(getenv("MPDATA_EXACT_FLUX"), "hbm");
   return exact_flux_in_order() && !hbm;
 }
+// The park array of an EXACT device call is kept per HOST THREAD and STREAM between calls (calls on one stream are ordered,
+// so they can share it; another stream gets its own).  Rounds 4-5 allocated it in stream order around every call
+// (hipMallocAsync / hipFreeAsync): on the legacy default stream that produced, once in ~50 runs of the fp32 Fortran
+// driver, a launch whose finishing kernel read something else than the main kernel had parked for ONE workgroup
+// (flux of 32 instances wrong, f right; never with a plain hipMalloc: round 5, 0 of 150 against 3 of 150).
+// mpdata_release_host_buffers() frees the calling thread's buffers; a thread that ends frees its own.
+struct ParkBuf {
+  int dev;
+  hipStream_t stream;
+  void* p;
+  size_t cap;
+};
+struct ParkCache {
+  ParkBuf b[8];
+  int n = 0;
+  void drop(int i) {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return;   // (the runtime is gone: process exit)
+    if (hipSetDevice(b[i].dev) == hipSuccess) {
+      (void)hipDeviceSynchronize();   // (the stream itself may have been destroyed by its owner)
+      (void)hipFree(b[i].p);
+      (void)hipSetDevice(cur);
+    }
+    b[i] = b[--n];
+  }
+  void release() {
+    while (n > 0) drop(n - 1);
+  }
+  ~ParkCache() { release(); }
+};
+thread_local ParkCache t_park;
+int park_buffer(hipStream_t stream, size_t bytes, void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  for (int i = 0; i < t_park.n; ++i)
+    if (t_park.b[i].dev == dev && t_park.b[i].stream == stream) {
+      if (t_park.b[i].cap >= bytes) { *out = t_park.b[i].p; return 0; }
+      t_park.drop(i);
+      break;
+    }
+  if (t_park.n == 8) t_park.drop(0);
+  void* p = nullptr;
+  const size_t cap = bytes + bytes / 4;
+  HIP_TRY(hipMalloc(&p, cap));
+  t_park.b[t_park.n++] = ParkBuf{dev, stream, p, cap};
+  *out = p;
+  return 0;
+}
+void park_buffers_release() { t_park.release(); }
+
 // var: MPDATA_VARIANT_* (a plan passes the variant it was created with; < 0: the global one)
 template <typename R>
 int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u, const R* w,
@@ -249,8 +299,9 @@ int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u,
   a.f_tstride = (long long)ncrms * (nx + 6) * (nz - 1);
   a.flux_tstride = (long long)ncrms * nz;
   a.dbg = g_dbg;
-  // EXACT, x-marching kernels: the park array of the bit-identical flux (see xmarch_flux_finish_kernel), allocated and
-  // freed in stream order around the launch: [workgroup][nx][thread].  (The k-marching kernels add in the reference's
+  // EXACT, x-marching kernels: the park array of the bit-identical flux (see xmarch_flux_finish_kernel), [workgroup][nx]
+  // [thread], where the register park does not apply (nx > 36, 16-wave workgroups): a buffer kept per host thread and
+  // stream (park_buffer).  (The k-marching kernels add in the reference's
   // order by construction; FAST never parks; MPDATA_EXACT_FLUX=sum does without.)
   a.wpark = nullptr;
   a.park_regs = 0;
@@ -262,7 +313,8 @@ int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u,
     const size_t groups = (size_t)((ncrms + t.slw - 1) / t.slw);
     const size_t esz = t.id >= 40 ? 8 : (size_t)t.elem_bytes;   // (tile ids 40..: two fp32 instances per lane)
     const size_t bytes = (size_t)ntracers * groups * (size_t)nx * (size_t)t.threads * esz;
-    HIP_TRY(hipMallocAsync(&park_mem, bytes, (hipStream_t)stream));
+    const int prc = park_buffer((hipStream_t)stream, bytes, &park_mem);
+    if (prc) return prc;
     a.wpark = (R*)park_mem;
   }
   bool ok;
@@ -272,7 +324,6 @@ int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u,
   else
     ok = var == MPDATA_VARIANT_FAST ? mpdata_fast::launch_f32(t.id, a, ntracers, stream)
                                     : mpdata_exact::launch_f32(t.id, a, ntracers, stream);
-  if (park_mem) (void)hipFreeAsync(park_mem, (hipStream_t)stream);
   if (!ok) return set_err(MPDATA_EINVAL, "tile %d not instantiated", t.id);
   HIP_TRY(hipGetLastError());
   return 0;

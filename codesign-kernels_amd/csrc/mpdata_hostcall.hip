@@ -89,6 +89,7 @@ bool host_cache_on() {
 }  // namespace
 
 int mpdata_release_host_buffers(void) {
+  park_buffers_release();   // (the park arrays of this thread's EXACT device calls)
   if (t_host.dev < 0) return 0;
   int cur = 0;
   hipError_t e = hipGetDevice(&cur);

@@ -86,6 +86,9 @@ extern template int advect_device<double>(int64_t, int, int, int, double*, const
 extern template int advect_device<float>(int64_t, int, int, int, float*, const float*, const float*, const float*,
                                          const float*, const float*, float*, void*, int);
 
+// frees the calling thread's park buffers of the EXACT device calls (mpdata_core.hip: park_buffer)
+void park_buffers_release();
+
 // the device a pointer lives on (the current one if HIP does not know the pointer)
 int device_of(const void* p);
 // switch to a device for a scope

@@ -108,16 +108,25 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
 #ifndef MPDATA_FAST_DIV
   // EXACT, bit-identical flux without a park array (round 5): the nx limited vertical fluxes of a lane stay in
   // REGISTERS (one tracer per wave, 2 waves per SIMD) and are added onto the finished upwind sum behind the march
-  if (a.park_regs && a.nx <= MPDATA_WM_NPK && !a.wpark) {
+  if (a.park_regs && a.nx <= MPDATA_WM_NPK2 && !a.wpark) {
+    const bool small = a.nx <= MPDATA_WM_NPK;   // (two instantiations: 36 columns at 187 registers, 66 at 247)
     if (a.ntracers == 1 && !no_stream) {
       const unsigned blocks = (unsigned)((a.ntiles + WPB - 1) / WPB);
-      hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, true, 1, false, false, MPDATA_WM_NPK>), dim3(blocks),
-                         dim3(64 * WPB), 0, (hipStream_t)stream, a);
+      if (small)
+        hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, true, 1, false, false, MPDATA_WM_NPK>), dim3(blocks),
+                           dim3(64 * WPB), 0, (hipStream_t)stream, a);
+      else
+        hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, true, 1, false, false, MPDATA_WM_NPK2>), dim3(blocks),
+                           dim3(64 * WPB), 0, (hipStream_t)stream, a);
     } else {   // tracer batches: one tracer per wave, the per-XCD tracer walk
       const long long per_xcd = ((long long)(a.ntiles + 7) / 8) * a.ntracers;
       const unsigned blocks = (unsigned)(8 * ((per_xcd + WPB - 1) / WPB));
-      hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false, 1, false, false, MPDATA_WM_NPK>), dim3(blocks),
-                         dim3(64 * WPB), 0, (hipStream_t)stream, a);
+      if (small)
+        hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false, 1, false, false, MPDATA_WM_NPK>), dim3(blocks),
+                           dim3(64 * WPB), 0, (hipStream_t)stream, a);
+      else
+        hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, LPS, WPB, false, 1, false, false, MPDATA_WM_NPK2>), dim3(blocks),
+                           dim3(64 * WPB), 0, (hipStream_t)stream, a);
     }
     return;
   }
@@ -187,6 +196,11 @@ static void launch_wm_ks(const MpdataWmArgsT<R>& a, void* stream) {
 #ifndef MPDATA_FAST_DIV
   if (a.park_regs && a.nx <= MPDATA_WM_NPK) {
     hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 1, false, false, MPDATA_WM_NPK>),
+                       dim3(blocks_for(a.ntracers)), dim3(threads), 0, (hipStream_t)stream, a);
+    return;
+  }
+  if (a.park_regs && a.nx <= MPDATA_WM_NPK2) {
+    hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 1, false, false, MPDATA_WM_NPK2>),
                        dim3(blocks_for(a.ntracers)), dim3(threads), 0, (hipStream_t)stream, a);
     return;
   }

@@ -267,9 +267,9 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   if (rc) return rc;
   const int var = variant();
   // wave-major: fp64, and fp32 with an even ncrms (two adjacent instances per lane = 8-byte elements)
-  // (nz > 64: EXACT with the flux in the reference's order needs the register park there: nx <= MPDATA_WM_NPK)
+  // (nz > 64: EXACT with the flux in the reference's order needs the register park there: nx <= MPDATA_WM_NPK2)
   const bool ks_ok = nz <= 64 || var != MPDATA_VARIANT_EXACT || !exact_flux_in_order() ||
-                     (exact_flux_in_regs() && nx <= MPDATA_WM_NPK);
+                     (exact_flux_in_regs() && nx <= MPDATA_WM_NPK2);
   const bool wmaj = (eb == 8 || (ncrms & 1) == 0) && wm_lps_for(nz) != 0 && ks_ok &&
                     plan_layout_default() == MPDATA_LAYOUT_WAVEMAJOR && tile_override() < 0;
   MpdataTileInfo t;
@@ -331,7 +331,7 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
     // EXACT: the park array of the limited vertical fluxes (bit-identical flux, see plan_flux_finish): [tracer][tile][nx][64]
     // 8-byte elements, the size of f's interior.  MPDATA_EXACT_FLUX=sum does without it (flux = upwind sum + limited sum,
     // <= 1e-13 relative, the behaviour up to round 3; a quarter faster in the EXACT variant).
-    p->park_regs = var == MPDATA_VARIANT_EXACT && exact_flux_in_regs() && nx <= MPDATA_WM_NPK;
+    p->park_regs = var == MPDATA_VARIANT_EXACT && exact_flux_in_regs() && nx <= MPDATA_WM_NPK2;
     if (e == hipSuccess && var == MPDATA_VARIANT_EXACT && exact_flux_in_order() && !p->park_regs) {
       p->wpark_bytes = (size_t)ntracers * p->ntiles * (size_t)nx * 64 * 8;
       e = hipMalloc(&p->wpark, p->wpark_bytes);

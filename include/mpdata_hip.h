@@ -53,14 +53,14 @@ extern "C" {
                                    the nx limited vertical fluxes of every lane
                                    and add them onto the FINISHED upwind sum one
                                    by one, the reference's order :545, :624:
-                                   at nx <= 36 in registers (plans, and device
-                                   calls with nz <= 32: no extra memory, no extra
-                                   kernel); the other cases -- nx > 36,
+                                   in registers (plans at nx <= 66, device calls
+                                   at nx <= 36 and nz <= 32: no extra memory, no
+                                   extra kernel); the other cases -- larger nx,
                                    mpdata_plan_run_uw, device calls with nz 33 ..
                                    64 -- in a park
                                    array of the size of f's interior per tracer
-                                   (with the plan, or allocated and freed in
-                                   stream order around a device call) that a
+                                   (with the plan, or kept per host thread and
+                                   stream for device calls) that a
                                    finishing kernel adds.  MPDATA_EXACT_FLUX=sum
                                    in the environment does without either
                                    (=hbm: the park array everywhere; device calls
@@ -87,7 +87,9 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers,
 /* The call keeps what it needs besides the caller's arrays -- two streams and up to three sets of chunk
  * buffers (3/8 of the arrays' size at the default chunking) -- for the next call of the same HOST
  * THREAD (creating and destroying them costs 6.7 ms per call).  This releases the calling thread's
- * set; a thread that ends releases its own; MPDATA_HOST_CACHE=0 in the environment keeps nothing. */
+ * set; a thread that ends releases its own; MPDATA_HOST_CACHE=0 in the environment keeps nothing.
+ * The same call releases the park arrays that EXACT calls on reference-layout DEVICE arrays keep per
+ * host thread and stream (only where the limited fluxes do not fit registers: nx > 36, nz 33 .. 64). */
 int mpdata_release_host_buffers(void);
 
 /* ---- 2. Device-resident call: device pointers, asynchronous on `stream`
@@ -111,7 +113,7 @@ int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers,
  * its own "wave-major" order -- [tile of 64/LPS adjacent instances][column]
  * [instance][level], LPS = 8/16/32/64 >= nz (nz > 64: one instance per tile, worked on by several waves) -- so that
  * every wave streams contiguous memory; upload / download / import / export
- * convert on the device.  Other plans (nz > 127; EXACT with nz > 64 and nx > 36; fp32 with an odd ncrms or nz > 64), MPDATA_PLAN_LAYOUT=
+ * convert on the device.  Other plans (nz > 127; EXACT with nz > 64 and nx > 66; fp32 with an odd ncrms or nz > 64), MPDATA_PLAN_LAYOUT=
  * reference or mpdata_set_plan_layout(MPDATA_LAYOUT_REFERENCE) keep the
  * reference layout.  Results do not depend on the layout. */
 #define MPDATA_LAYOUT_REFERENCE 0

@@ -195,3 +195,26 @@ def test_driver_device_mode(oracle, ntr, ngpus, fake_rccl):
     assert ranks == (ngpus if fake_rccl else 0)
     if ngpus > 1:
         assert "scatter seconds" in res.stdout and "gather  seconds" in res.stdout
+
+
+@pytest.mark.gpu
+def test_park_array_of_the_device_call_is_stable_over_many_processes(oracle, tmp_path):
+    """Round 5 regression: the EXACT device call parks the limited vertical fluxes in HBM where they do not fit registers
+    (here: the fp32 one-instance-per-lane kernel, a 16-wave workgroup).  With the park array allocated in stream order
+    around every call (hipMallocAsync / hipFreeAsync on the legacy default stream) about one process in fifty delivered
+    a flux whose limited part belonged to nothing for ONE workgroup (f right).  The array is kept per host thread and
+    stream now: 60 fresh processes, flux bit-identical every time."""
+    assert os.path.exists(EXE_SP), "single-precision Fortran driver not built"
+    ncrms, nx, nz, dist = 101, 32, 28, 3
+    inp = oracle.make_inputs(ncrms, nx, nz, seed=100, dist=dist, dtype=np.float32)
+    f_ref, flux_ref = oracle.advect(inp)
+    dump = tmp_path / "out.bin"
+    for rep in range(60):
+        res = subprocess.run([EXE_SP, str(ncrms), str(nx), str(nz), str(dist), "0", str(dump)], capture_output=True, text=True,
+                             timeout=120)
+        assert res.returncode == 0, res.stdout + res.stderr
+        raw = np.fromfile(dump, dtype=np.float32)
+        f = raw[:f_ref.size].reshape(f_ref.shape, order="F")
+        flux = raw[f_ref.size:].reshape(flux_ref.shape, order="F")
+        assert np.array_equal(f, f_ref), rep
+        assert np.array_equal(flux[:, :nz - 1], flux_ref[:, :nz - 1]), rep

@@ -84,11 +84,16 @@ def test_tracer_batches_above_64_levels(mpdata, oracle, shape, ntr, variant):
 
 
 def test_exact_with_more_columns_than_the_register_park_holds(mpdata, oracle):
-    """EXACT with nx > 36 at nz > 64: the bit-identical flux has no form there -- the plan falls back to the reference
-    layout (k-marching kernel, bit-identical by construction) instead of delivering another flux."""
+    """EXACT with nx > 66 at nz > 64: the bit-identical flux has no form there (the register park holds 36 or 66 columns)
+    -- the plan falls back to the reference layout (k-marching kernel, bit-identical by construction) instead of
+    delivering another flux; nx = 40 takes the 66-column park."""
     M = mpdata
     M.set_variant(M.VARIANT_EXACT)
-    shape = (5, 40, 70)
+    inp40 = oracle.make_inputs(5, 40, 70, seed=5, dist=3)
+    f40, fl40 = _run(M, inp40)
+    fr40, flr40 = oracle.advect(inp40, nthreads=4)
+    assert np.array_equal(f40, fr40) and np.array_equal(fl40, flr40)
+    shape = (5, 70, 70)
     inp = oracle.make_inputs(*shape, seed=5, dist=3)
     p = M.Plan(*shape, 1)
     assert p.layout == M.LAYOUT_REFERENCE

@@ -90,7 +90,8 @@ def test_wavemajor_plan_reproduces_reference_golden_bitwise(M, oracle, case):
 # fewer tiles than a workgroup holds), odd nx (a last pair with one column), the smallest
 # shapes the routine is defined for, nz at the top of each LPS class, the shipped size
 SHAPES = [(64, 32, 28), (48, 32, 58), (1, 1, 3), (3, 1, 3), (7, 2, 4), (5, 3, 8), (19, 5, 9), (33, 7, 16),
-          (37, 32, 17), (129, 9, 32), (21, 33, 33), (10, 6, 64), (131, 4, 28), (258, 31, 28), (100, 66, 28)]
+          (37, 32, 17), (129, 9, 32), (21, 33, 33), (10, 6, 64), (131, 4, 28), (258, 31, 28), (100, 66, 28), (40, 70, 28),
+          (33, 37, 58)]   # (nx: <= 36 / <= 66 the two register-park instantiations of EXACT, beyond: the park array)
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
