@@ -234,7 +234,10 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   // the 7-operation extrema (stage A below): where the registers allow it (the u, w-ring form with one instance per
   // wave, LPS = 64, and its converting form UWCONV are two registers short: they keep the merged ring value and take
   // the extrema as written)
-  constexpr bool XNEW = TPW == 2 || T1X || (UWX2 && LW < 64 && !UWCONV);
+  // (the register-park form of EXACT runs in a 256-register budget like the two-tracer form: it takes them too -- the
+  //  extremum of a set does not depend on the order, the results are the same bits; -1.1 % one tracer and 25, interleaved:
+  //  profiles/r05_ab_exact_extrema.txt)
+  constexpr bool XNEW = TPW == 2 || T1X || (UWX2 && LW < 64 && !UWCONV) || NPK > 0;
   // FAST, two tracers per wave (the VALU- / power-bound form): three operations per tracer and column fewer
   // by carrying sums in the rings and sharing the velocity parts of the upwind fluxes (below: XSUM)
   constexpr bool XSUM = FASTV && XNEW && !UWX2;
