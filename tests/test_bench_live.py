@@ -22,6 +22,13 @@ def test_live_line_meets_the_contract():
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    # the driver keeps a 10-KB tail of the line for its reader: the line stays compact and the blocks of the hot path
+    # come last (side kernels and secondary views first)
+    assert len(lines[0]) < 16000, len(lines[0])
+    keys = list(d)
+    assert keys.index("tracer_batched") > keys.index("consecutive_tracers_shared_uw") > keys.index("layout_conversion")
+    assert keys.index("exact_variant") > keys.index("cpu_baseline") > keys.index("consecutive_tracers_shared_uw")
+    assert keys[-1] == "tracer_batched" and keys.index("roofline") < keys.index("layout_conversion")
     C.check_headline(d, 8192)
     C.check_roofline(d, 8192)
     C.check_cpu_baseline(d)
