@@ -352,10 +352,11 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   [[maybe_unused]] R PK[NPK > 0 ? NPK : 1];   // REG_PARK: limited vertical flux of column i = PK[i - 1] (constant indices only: registers)
   [[maybe_unused]] const bool park = CAN_PARK && a.wpark != nullptr;
   [[maybe_unused]] const long long parkB = (long long)nx * 64 * RB;   // bytes of one (tracer, tile) block
+  // (KS: a block per wave of the instance, [tracer][tile][wave][column][lane]; a.nkw = 1 otherwise)
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsp = v2::make_rsrc(
-      a.wpark + ((long long)tr * a.ntiles + tile) * ((long long)nx * 64), (park && tile_ok) ? parkB : 0);
+      a.wpark + (((long long)tr * a.ntiles + tile) * a.nkw + kwave) * ((long long)nx * 64), (park && tile_ok) ? parkB : 0);
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsp1 = v2::make_rsrc(
-      a.wpark + ((long long)(tr + 1) * a.ntiles + tile) * ((long long)nx * 64), (park && has1) ? parkB : 0);
+      a.wpark + (((long long)(tr + 1) * a.ntiles + tile) * a.nkw + kwave) * ((long long)nx * 64), (park && has1) ? parkB : 0);
   [[maybe_unused]] auto park_st = [&](const int col, const V w3) __attribute__((always_inline)) {   // col = 1 .. nx
     unsigned z;   // (the lane's byte offset formed from the execution mask here: no register carries it through the march)
     asm volatile("s_mov_b32 %0, 0" : "=s"(z));

@@ -25,14 +25,22 @@ namespace {
 // -ffp-contract=off).
 template <typename R2>
 __global__ void __launch_bounds__(256) flux_finish_kernel(R2* flux, const R2* park, int ntiles, int nx, int nzm, int lps,
-                                                          long long flux_tstride, int ntr) {
+                                                          long long flux_tstride, int ntr, int nkw) {
   const int lane = threadIdx.x & 63;
-  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // wave = tracer * ntiles + tile
-  if (w >= (long long)ntr * ntiles) return;
-  const int tr = (int)(w / ntiles), tile = (int)(w % ntiles);
-  const int s_l = lane / lps, kk = lane % lps;
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // wave = (tracer * ntiles + tile) * nkw + wave of the instance
+  if (w >= (long long)ntr * ntiles * nkw) return;
+  const int h = (int)(w % nkw);
+  const long long tt = w / nkw;
+  const int tr = (int)(tt / ntiles), tile = (int)(tt % ntiles);
+  int s_l = lane / lps, kk = lane % lps, chunk = (64 / lps) * nzm;
+  if (lps > 64) {   // nz > 64: the wave's 64-level window and the part of it the plan kernel stores (mpdata_kernel_wm_body.h: koff, out_ok)
+    const int nz = nzm + 1;
+    const int koff = min(58 * h, max(0, (nz - 64 + 1) & ~1));
+    s_l = 0; kk = lane + koff; chunk = nzm;
+    const int k = kk + 1;
+    if (!((h == 0 || k >= 58 * h + 4) && (h + 1 == nkw || k <= 58 * h + 61))) return;
+  }
   if (kk >= nzm) return;
-  const int chunk = (64 / lps) * nzm;
   R2* fp = flux + (long long)tr * flux_tstride + (long long)tile * chunk + s_l * nzm + kk;
   const R2* pp = park + w * ((long long)nx * 64) + lane;
   R2 acc = *fp;
@@ -267,10 +275,7 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
   if (rc) return rc;
   const int var = variant();
   // wave-major: fp64, and fp32 with an even ncrms (two adjacent instances per lane = 8-byte elements)
-  // (nz > 64: EXACT with the flux in the reference's order needs the register park there: nx <= MPDATA_WM_NPK2)
-  const bool ks_ok = nz <= 64 || var != MPDATA_VARIANT_EXACT || !exact_flux_in_order() ||
-                     (exact_flux_in_regs() && nx <= MPDATA_WM_NPK2);
-  const bool wmaj = (eb == 8 || (ncrms & 1) == 0) && wm_lps_for(nz) != 0 && ks_ok &&
+  const bool wmaj = (eb == 8 || (ncrms & 1) == 0) && wm_lps_for(nz) != 0 &&
                     plan_layout_default() == MPDATA_LAYOUT_WAVEMAJOR && tile_override() < 0;
   MpdataTileInfo t;
   if (!wmaj) {
@@ -333,7 +338,7 @@ static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan*
     // <= 1e-13 relative, the behaviour up to round 3; a quarter faster in the EXACT variant).
     p->park_regs = var == MPDATA_VARIANT_EXACT && exact_flux_in_regs() && nx <= MPDATA_WM_NPK2;
     if (e == hipSuccess && var == MPDATA_VARIANT_EXACT && exact_flux_in_order() && !p->park_regs) {
-      p->wpark_bytes = (size_t)ntracers * p->ntiles * (size_t)nx * 64 * 8;
+      p->wpark_bytes = (size_t)ntracers * p->ntiles * wm_nkw_for(nz) * (size_t)nx * 64 * 8;
       e = hipMalloc(&p->wpark, p->wpark_bytes);
       if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -451,14 +456,14 @@ int mpdata_plan_export_device(mpdata_plan* p, void* f, void* flux, int first_tra
 // (EXACT wave-major runs: the finishing kernel of the bit-identical flux, behind the plan kernels on the same stream)
 static int plan_flux_finish(mpdata_plan* p, const MpdataWmArgs& a, int count) {
   if (!a.wpark) return 0;
-  const long long waves = (long long)count * p->ntiles;
+  const long long waves = (long long)count * p->ntiles * a.nkw;
   const unsigned blocks = (unsigned)((waves + 3) / 4);
   if (p->eb == 8)
     hipLaunchKernelGGL(flux_finish_kernel<double>, dim3(blocks), dim3(256), 0, p->stream, a.flux, (const double*)a.wpark, p->ntiles,
-                       p->nx, p->nz - 1, p->lps, a.flux_tstride, count);
+                       p->nx, p->nz - 1, p->lps, a.flux_tstride, count, a.nkw);
   else
     hipLaunchKernelGGL(flux_finish_kernel<float2>, dim3(blocks), dim3(256), 0, p->stream, (float2*)a.flux, (const float2*)a.wpark,
-                       p->ntiles, p->nx, p->nz - 1, p->lps, a.flux_tstride, count);
+                       p->ntiles, p->nx, p->nz - 1, p->lps, a.flux_tstride, count, a.nkw);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -485,7 +490,7 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
     if (u_ref && p->park_regs && !p->wpark) {
       // the kernel that reads u, w from the reference layout has no register-park form (its EXACT build takes every
       // register it can get): the park array after all, allocated by the first such call
-      p->wpark_bytes = (size_t)p->ntracers * p->ntiles * (size_t)p->nx * 64 * 8;
+      p->wpark_bytes = (size_t)p->ntracers * p->ntiles * wm_nkw_for(p->nz) * (size_t)p->nx * 64 * 8;
       const hipError_t e = hipMalloc(&p->wpark, p->wpark_bytes);
       if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -494,7 +499,7 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
                                "MPDATA_EXACT_FLUX=sum does without it", p->wpark_bytes / 1e9);
       }
     }
-    a.wpark = (p->wpark && !a.park_regs) ? (double*)p->wpark + (long long)first * p->ntiles * ((long long)p->nx * 64) : nullptr;
+    a.wpark = (p->wpark && !a.park_regs) ? (double*)p->wpark + (long long)first * p->ntiles * a.nkw * ((long long)p->nx * 64) : nullptr;
     const bool fast = p->variant == MPDATA_VARIANT_FAST;
     if (u_ref) {
       a.reverse = 0;

@@ -109,11 +109,11 @@ int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers,
  * fixes the kernel variant at creation.
  *
  * Device layout.  The arrays a caller passes are ALWAYS in the reference
- * layout above.  Inside a plan with nz <= 127 (fp64; fp32 with an even ncrms and nz <= 64) the library keeps them in
+ * layout above.  Inside a plan with nz <= 127 (fp64; fp32 with an even ncrms) the library keeps them in
  * its own "wave-major" order -- [tile of 64/LPS adjacent instances][column]
  * [instance][level], LPS = 8/16/32/64 >= nz (nz > 64: one instance per tile, worked on by several waves) -- so that
  * every wave streams contiguous memory; upload / download / import / export
- * convert on the device.  Other plans (nz > 127; EXACT with nz > 64 and nx > 66; fp32 with an odd ncrms or nz > 64), MPDATA_PLAN_LAYOUT=
+ * convert on the device.  Other plans (nz > 127; fp32 with an odd ncrms), MPDATA_PLAN_LAYOUT=
  * reference or mpdata_set_plan_layout(MPDATA_LAYOUT_REFERENCE) keep the
  * reference layout.  Results do not depend on the layout. */
 #define MPDATA_LAYOUT_REFERENCE 0

@@ -5,7 +5,7 @@ it, each on 64 levels of its own, NOTHING crosses between them -- the routine's 
 (csrc/mpdata_kernel_wm_body.h, kernel form LPS = 128).  Up to round 4 such plans fell back to the k-marching kernel
 of round 1 (10-30 % of the headline's rate).
 
-Bars as everywhere: EXACT f AND flux bit-identical to the oracle (flux through the register park: nx <= 36),
+Bars as everywhere: EXACT f AND flux bit-identical to the oracle (flux through the register parks at nx <= 66, the park array beyond),
 FAST max|d| < 1e-12 on conditioned inputs; the output contract on the whole arrays."""
 import numpy as np
 import pytest
@@ -83,32 +83,50 @@ def test_tracer_batches_above_64_levels(mpdata, oracle, shape, ntr, variant):
             assert max_abs(f[..., t], f_ref) < 1e-12 and max_abs(flux[..., t], flux_ref) < 1e-12
 
 
-def test_exact_with_more_columns_than_the_register_park_holds(mpdata, oracle):
-    """EXACT with nx > 66 at nz > 64: the bit-identical flux has no form there (the register park holds 36 or 66 columns)
-    -- the plan falls back to the reference layout (k-marching kernel, bit-identical by construction) instead of
-    delivering another flux; nx = 40 takes the 66-column park."""
+@pytest.mark.parametrize("shape,ntr", [((5, 70, 70), 1), ((7, 67, 72), 1), ((3, 100, 127), 1), ((4, 130, 65), 1), ((5, 80, 100), 3)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_exact_with_more_columns_than_the_register_park_holds(mpdata, oracle, shape, ntr):
+    """EXACT with nx > 66 at nz > 64: the register park holds 36 or 66 columns; beyond, every wave of an instance parks the
+    limited fluxes of its window in HBM ([tracer][instance][wave][column][lane]) and the finishing kernel adds the rows a
+    wave owns in the reference's order -- wave-major (round 5 fell back to the k-marching kernel here: 12 Gcu/s), f and
+    flux bit-identical."""
     M = mpdata
     M.set_variant(M.VARIANT_EXACT)
-    inp40 = oracle.make_inputs(5, 40, 70, seed=5, dist=3)
-    f40, fl40 = _run(M, inp40)
-    fr40, flr40 = oracle.advect(inp40, nthreads=4)
-    assert np.array_equal(f40, fr40) and np.array_equal(fl40, flr40)
-    shape = (5, 70, 70)
-    inp = oracle.make_inputs(*shape, seed=5, dist=3)
-    p = M.Plan(*shape, 1)
-    assert p.layout == M.LAYOUT_REFERENCE
+    base = oracle.make_inputs(*shape, seed=5, dist=3)
+    fs = [oracle.make_inputs(*shape, seed=50 + t, dist=3)["f"] for t in range(ntr)]
+    inp = dict(base)
+    if ntr > 1:
+        inp["f"] = np.asfortranarray(np.stack(fs, axis=-1))
+        inp["flux"] = np.asfortranarray(np.stack([base["flux"]] * ntr, axis=-1))
+    else:
+        inp["f"] = fs[0]
+    p = M.Plan(*shape, ntr)
+    assert p.layout == M.LAYOUT_WAVEMAJOR
     p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
     p.run(); p.sync()
     f = np.empty_like(inp["f"], order="F"); flux = np.empty_like(inp["flux"], order="F")
     p.download(f, flux)
     p.close()
-    f_ref, flux_ref = oracle.advect(inp, nthreads=4)
-    assert np.array_equal(f, f_ref) and np.array_equal(flux, flux_ref)
-    # FAST has no flux order to keep: wave-major at any nx
-    M.set_variant(M.VARIANT_FAST)
-    p = M.Plan(*shape, 1)
+    for t in range(ntr):
+        f_ref, flux_ref = oracle.advect(dict(base, f=fs[t].copy()), nthreads=4)
+        ft, flt = (f[..., t], flux[..., t]) if ntr > 1 else (f, flux)
+        assert np.array_equal(ft, f_ref) and np.array_equal(flt, flux_ref)
+
+
+def test_exact_fp32_with_more_columns_than_the_register_park_holds(mpdata, oracle):
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    shape = (6, 75, 90)
+    inp = oracle.make_inputs(*shape, seed=9, dist=1, dtype=np.float32)
+    p = M.Plan(*shape, 1, dtype=np.float32)
     assert p.layout == M.LAYOUT_WAVEMAJOR
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run(); p.sync()
+    f = np.empty_like(inp["f"], order="F"); flux = np.empty_like(inp["flux"], order="F")
+    p.download(f, flux)
     p.close()
+    f_ref, flux_ref = oracle.advect(inp)
+    assert np.array_equal(f, f_ref) and np.array_equal(flux, flux_ref)
 
 
 def test_run_uw_and_device_import_above_64_levels(mpdata, oracle):

@@ -396,7 +396,7 @@ def test_exact_flux_through_the_park_array_everywhere(oracle):
         "from util import run_hip\n"
         "O.build_lib(); M.set_variant(M.VARIANT_EXACT)\n"
         "ok = True\n"
-        "for shape, T in (((130, 31, 28), 1), ((37, 9, 17), 3)):\n"
+        "for shape, T in (((130, 31, 28), 1), ((37, 9, 17), 3), ((9, 20, 72), 2), ((5, 11, 125), 1)):\n"
         "    base = O.make_inputs(*shape, seed=5, dist=3)\n"
         "    fs = [O.make_inputs(*shape, seed=50 + t, dist=3)['f'] for t in range(T)]\n"
         "    inp = dict(base)\n"

@@ -31,7 +31,8 @@ def rshape(nzmax):
     nx = int(rng.integers(1, 41))
     if nz > 64:
         ncrms = min(ncrms, 200)
-        nx = min(nx, 36)      # (EXACT with the ordered flux: the register park)
+        if rng.integers(0, 4) == 0:
+            nx = int(rng.integers(67, 100))      # (EXACT: beyond both register parks -> the park array of the window form)
     return ncrms, nx, nz
 
 
