@@ -284,12 +284,14 @@ void park_buffers_release() { t_park.release(); }
 // var: MPDATA_VARIANT_* (a plan passes the variant it was created with; < 0: the global one)
 template <typename R>
 int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u, const R* w,
-                  const R* rho, const R* rhow, const R* adz, R* flux, void* stream, int var) {
+                  const R* rho, const R* rhow, const R* adz, R* flux, void* stream, int var, bool staged) {
   int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
   if (!f || !u || !w || !rho || !rhow || !adz || !flux)
     return set_err(MPDATA_EINVAL, "null array pointer");
   if (var < 0) var = variant();
+  if (staged && staged_call_applies(ncrms, nz, (int)sizeof(R)))   // 65 <= nz <= 127: through a wave-major plan (mpdata_plan.hip)
+    return staged_device_call((int)sizeof(R), ncrms, nx, nz, ntracers, f, u, w, rho, rhow, adz, flux, stream, var);
   MpdataTileInfo t;
   rc = choose_tile(var, ncrms, nx, nz, &t, (int)sizeof(R));
   if (rc) return rc;
@@ -368,9 +370,9 @@ int fill_device(R* a, int sid, int64_t rows, int64_t ncrms_global, int64_t sl0, 
 }
 
 template int advect_device<double>(int64_t, int, int, int, double*, const double*, const double*, const double*,
-                                   const double*, const double*, double*, void*, int);
+                                   const double*, const double*, double*, void*, int, bool);
 template int advect_device<float>(int64_t, int, int, int, float*, const float*, const float*, const float*,
-                                  const float*, const float*, float*, void*, int);
+                                  const float*, const float*, float*, void*, int, bool);
 
 int g_layout = -1;  // -1: read MPDATA_PLAN_LAYOUT on first use
 int plan_layout_default() {

@@ -90,6 +90,7 @@ bool host_cache_on() {
 
 int mpdata_release_host_buffers(void) {
   park_buffers_release();   // (the park arrays of this thread's EXACT device calls)
+  staged_plan_release();    // (the plan behind this thread's device calls at nz > 64)
   if (t_host.dev < 0) return 0;
   int cur = 0;
   hipError_t e = hipGetDevice(&cur);
@@ -202,7 +203,10 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers, double* 
     h2d(b.flux, flux, rows_x);  // level nz is never written (reference :541,:624): carry it through
     if (e != hipSuccess) break;
     if (c == 0) mark("first chunk: host -> device queued");
-    rc = mpdata_advect_scalar2d_device(cw, nx, nz, ntracers, b.f, b.u, b.w, b.rho, b.rhow, b.adz, b.flux, (void*)s_in);
+    // (nz > 64: a device call may go through a plan kept per thread and SHAPE -- chunks of two widths would rebuild it
+    //  twice per call, and the transfers bound this path anyway: only where nothing else runs the shape)
+    rc = advect_device<double>(cw, nx, nz, ntracers, b.f, b.u, b.w, b.rho, b.rhow, b.adz, b.flux, (void*)s_in, -1,
+                               !piped || nx > 140);
     if (rc) break;
     if (c == 0) mark("first chunk: kernel queued");
     if (!piped) {

@@ -77,17 +77,24 @@ hipError_t arena_place(Arena& a, size_t& cap, const size_t bytes[7]);
 bool exact_flux_in_order();
 bool exact_flux_in_regs();
 
-// one call on reference-layout device arrays (x-march / k-march kernels); var: MPDATA_VARIANT_* (< 0: the global one)
+// one call on reference-layout device arrays (x-march / k-march kernels); var: MPDATA_VARIANT_* (< 0: the global one);
+// staged: 65 <= nz <= 127 may go through the calling thread's wave-major plan (staged_device_call below)
 template <typename R>
 int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u, const R* w, const R* rho, const R* rhow,
-                  const R* adz, R* flux, void* stream, int var = -1);
+                  const R* adz, R* flux, void* stream, int var = -1, bool staged = true);
 extern template int advect_device<double>(int64_t, int, int, int, double*, const double*, const double*, const double*,
-                                          const double*, const double*, double*, void*, int);
+                                          const double*, const double*, double*, void*, int, bool);
 extern template int advect_device<float>(int64_t, int, int, int, float*, const float*, const float*, const float*,
-                                         const float*, const float*, float*, void*, int);
+                                         const float*, const float*, float*, void*, int, bool);
 
 // frees the calling thread's park buffers of the EXACT device calls (mpdata_core.hip: park_buffer)
 void park_buffers_release();
+// calls on reference-layout device arrays at 65 <= nz <= 127 through a wave-major plan kept per host thread
+// (mpdata_plan.hip); eb = bytes per real
+bool staged_call_applies(int64_t ncrms, int nz, int eb);
+int staged_device_call(int eb, int64_t ncrms, int nx, int nz, int ntracers, void* f, const void* u, const void* w, const void* rho,
+                       const void* rhow, const void* adz, void* flux, void* stream, int var);
+void staged_plan_release();
 
 // the device a pointer lives on (the current one if HIP does not know the pointer)
 int device_of(const void* p);

@@ -268,12 +268,12 @@ int plan_export(mpdata_plan* p, void* f, void* flux, int first, int count, bool 
 
 extern "C" {
 
-static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan, int eb) {
+static int plan_create(int64_t ncrms, int nx, int nz, int ntracers, mpdata_plan** plan, int eb, int var_in = -1) {
   if (!plan) return set_err(MPDATA_EINVAL, "null plan pointer");
   *plan = nullptr;
   int rc = validate(ncrms, nx, nz, ntracers);
   if (rc) return rc;
-  const int var = variant();
+  const int var = var_in >= 0 ? var_in : variant();
   // wave-major: fp64, and fp32 with an even ncrms (two adjacent instances per lane = 8-byte elements)
   const bool wmaj = (eb == 8 || (ncrms & 1) == 0) && wm_lps_for(nz) != 0 &&
                     plan_layout_default() == MPDATA_LAYOUT_WAVEMAJOR && tile_override() < 0;
@@ -756,6 +756,68 @@ int mpdata_plan_destroy(mpdata_plan* p) {
   if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
   free(p);
   return 0;
+}
+
+// ---- calls on reference-layout device arrays with 65 <= nz <= 127 (round 5).  No x-marching kernel holds such an
+//      instance in a wave and the k-marching fall-back runs at 13-16 Gcu/s (fp64, nx <= 140 only; fp32: nothing).  Such
+//      a call goes through a wave-major plan kept per host thread instead: import f, u, w, rho, rhow, adz, flux
+//      (the layout kernels), the plan kernel (several waves per instance), export f and flux -- everything on the
+//      caller's stream, asynchronous as the direct call is, same results (EXACT bit-identical incl. flux; flux(:,nz)
+//      carried through).  Costs the plan's memory (as much again as the call's arrays) until
+//      mpdata_release_host_buffers() or the end of the thread; MPDATA_DEVICE_CALL=direct keeps the k-marching kernel.
+namespace {
+struct StagedPlan {
+  mpdata_plan* p = nullptr;
+  int var = -1;
+  void release() {
+    if (!p) return;
+    int cur = 0;
+    if (hipGetDevice(&cur) == hipSuccess) mpdata_plan_destroy(p);   // (else the runtime is gone: process exit)
+    p = nullptr;
+  }
+  ~StagedPlan() { release(); }
+};
+thread_local StagedPlan t_staged;
+}  // namespace
+extern "C++" void mpd::staged_plan_release() { t_staged.release(); }
+extern "C++" bool mpd::staged_call_applies(int64_t ncrms, int nz, int eb) {
+  static const bool direct = getenv("MPDATA_DEVICE_CALL") && !strcmp(getenv("MPDATA_DEVICE_CALL"), "direct");
+  return !direct && nz > 64 && wm_lps_for(nz) != 0 && (eb == 8 || (ncrms & 1) == 0) &&
+         plan_layout_default() == MPDATA_LAYOUT_WAVEMAJOR && tile_override() < 0;
+}
+extern "C++" int mpd::staged_device_call(int eb, int64_t ncrms, int nx, int nz, int ntracers, void* f, const void* u, const void* w,
+                                         const void* rho, const void* rhow, const void* adz, void* flux, void* stream, int var) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  mpdata_plan* p = t_staged.p;
+  if (p && !(p->ncrms == ncrms && p->nx == nx && p->nz == nz && p->ntracers == ntracers && p->eb == eb && p->variant == var &&
+             p->device == dev)) {
+    t_staged.release();
+    p = nullptr;
+  }
+  if (!p) {
+    const int rc = plan_create(ncrms, nx, nz, ntracers, &p, eb, var);
+    if (rc) return rc;
+    if (p->layout != MPDATA_LAYOUT_WAVEMAJOR) {   // (staged_call_applies and plan_create disagree: a bug, not a fall-back)
+      mpdata_plan_destroy(p);
+      return set_err(MPDATA_EINVAL, "internal: staged device call without a wave-major plan");
+    }
+    (void)hipStreamDestroy(p->stream);
+    p->stream = (hipStream_t)stream;
+    p->own_stream = false;
+    p->timing = false;
+    t_staged.p = p;
+  }
+  if (p->stream != (hipStream_t)stream) {   // the previous call's work may still use the plan's arrays
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->stream = (hipStream_t)stream;
+  }
+  int rc = plan_import(p, f, u, w, rho, rhow, adz, flux, 0, ntracers, true);
+  if (rc) return rc;
+  p->uploaded = true;
+  rc = plan_launch(p, 0, ntracers);
+  if (rc) return rc;
+  return plan_export(p, f, flux, 0, ntracers, true);
 }
 
 // ... on the device a plan's full-width arrays must live on: the plan's own device, the ROOT GPU

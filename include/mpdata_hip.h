@@ -89,14 +89,20 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers,
  * THREAD (creating and destroying them costs 6.7 ms per call).  This releases the calling thread's
  * set; a thread that ends releases its own; MPDATA_HOST_CACHE=0 in the environment keeps nothing.
  * The same call releases the park arrays that EXACT calls on reference-layout DEVICE arrays keep per
- * host thread and stream (only where the limited fluxes do not fit registers: nx > 36, nz 33 .. 64). */
+ * host thread and stream (only where the limited fluxes do not fit registers: nx > 36, nz 33 .. 64), and
+ * the wave-major plan that calls on reference-layout device arrays with 65 <= nz <= 127 run through
+ * (the size of the call's arrays; kept per host thread for the next call of the same shape). */
 int mpdata_release_host_buffers(void);
 
 /* ---- 2. Device-resident call: device pointers, asynchronous on `stream`
  * (a hipStream_t passed as void*; NULL = the default stream).  This is the
  * reference's timed region (:110-238: kernels only, data already on the
  * device).  Arrays cover `ncrms` CRM instances with leading dimension
- * `ncrms`.  In-place on f. */
+ * `ncrms`.  In-place on f.  nz <= 64: one kernel on the caller's arrays.
+ * 65 <= nz <= 127: through a wave-major plan kept per host thread (import,
+ * plan kernel, export, all on `stream`; the first call of a shape allocates;
+ * MPDATA_DEVICE_CALL=direct: the k-marching kernel on the caller's arrays,
+ * a third of the rate).  nz > 127: the k-marching kernel (fp64, nx <= 140). */
 int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers,
                                   double* f, const double* u, const double* w,
                                   const double* rho, const double* rhow,

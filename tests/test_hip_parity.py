@@ -105,8 +105,8 @@ def test_every_tiling_config1_and_config2(M, oracle, tile, variant):
 @pytest.mark.parametrize("variant", [0, 1], ids=["exact", "fast"])
 def test_ragged_and_edge_shapes(M, oracle, shape, variant):
     """ncrms not a multiple of the tile, minimum nz (=3), every lanes-per-instance
-    boundary of the x-marching kernels (nz = 8/9, 16/17, 32/33, 64), nz > 64 (falls
-    back to the k-marching kernels), nx from 1 to 300, the reference's shipped
+    boundary of the x-marching kernels (nz = 8/9, 16/17, 32/33, 64), nz > 64 (through the
+    calling thread's wave-major plan since round 5; the k-marching kernels: the forced tilings above), nx from 1 to 300, the reference's shipped
     nz=58; signed velocities."""
     M.set_tile(-1)
     for dist in (oracle.DIST_CONDITIONED, oracle.DIST_RAW_SIGNED):

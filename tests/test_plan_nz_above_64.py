@@ -302,3 +302,101 @@ def test_sibling_waves_do_not_overtake_each_other(mpdata, oracle, variant, nz, n
                 assert np.array_equal(fg, fr) and np.array_equal(flg, flr)
             else:
                 assert max_abs(fg, fr) < 1e-12 and max_abs(flg[:, :nzm], flr[:, :nzm]) < 1e-12
+
+
+# ---- calls on reference-layout DEVICE arrays (mpdata_advect_scalar2d_device, the Fortran drivers' call) at nz 65 .. 127:
+#      through a wave-major plan the library keeps per host thread (csrc/mpdata_plan.hip: staged_device_call) -- up to
+#      round 5 the k-marching kernel (13-16 Gcu/s; fp32 and nx > 140: MPDATA_EUNSUPPORTED)
+def _stack(oracle, shape, ntr, dtype=np.float64, dist=3):
+    base = oracle.make_inputs(*shape, seed=5, dist=dist, dtype=dtype)
+    fs = [oracle.make_inputs(*shape, seed=50 + t, dist=dist, dtype=dtype)["f"] for t in range(ntr)]
+    inp = dict(base)
+    if ntr > 1:
+        inp["f"] = np.asfortranarray(np.stack(fs, axis=-1))
+        inp["flux"] = np.asfortranarray(np.stack([base["flux"]] * ntr, axis=-1))
+    else:
+        inp["f"] = fs[0]
+    return base, fs, inp
+
+
+@pytest.mark.parametrize("shape,ntr", [((9, 32, 72), 1), ((4, 150, 70), 1), ((3, 7, 127), 1), ((21, 12, 100), 3), ((5, 70, 66), 2)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_device_call_above_64_levels(mpdata, oracle, shape, ntr, variant):
+    """whole arrays against the oracle (f's halo columns and flux(:, nz) are the caller's): EXACT bit-identical incl. flux,
+    FAST < 1e-12; nx = 150 is beyond the widest k-marching tiling (an error up to round 5)"""
+    from util import run_hip
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST)
+    base, fs, inp = _stack(oracle, shape, ntr, dist=3 if variant == "exact" else 1)
+    f, flux = run_hip(M, inp)
+    for t in range(ntr):
+        f_ref, flux_ref = oracle.advect(dict(base, f=fs[t].copy()), nthreads=4)
+        ft, flt = (f[..., t], flux[..., t]) if ntr > 1 else (f, flux)
+        if variant == "exact":
+            assert np.array_equal(ft, f_ref) and np.array_equal(flt, flux_ref)
+        else:
+            assert max_abs(ft, f_ref) < 1e-12 and max_abs(flt, flux_ref) < 1e-12
+    M.release_host_buffers()
+
+
+def test_fp32_device_call_above_64_levels(mpdata, oracle):
+    from util import run_hip
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    for shape in ((6, 10, 65), (10, 9, 72), (8, 40, 127)):
+        inp = oracle.make_inputs(*shape, seed=3, dist=1, dtype=np.float32)
+        f, flux = run_hip(M, inp)
+        f_ref, flux_ref = oracle.advect(inp)
+        assert np.array_equal(f, f_ref) and np.array_equal(flux, flux_ref), shape
+    M.release_host_buffers()
+
+
+def test_device_calls_of_changing_shape_stream_and_variant(mpdata, oracle):
+    """the plan behind these calls is kept per host thread and rebuilt when the shape, the tracer count, the precision or
+    the variant changes; a call on another stream waits for the previous one's work on the plan's arrays; releasing the
+    buffers in between is harmless; the same call twice gives the same answer (the plan's state does not leak)"""
+    import torch
+    M = mpdata
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    cases = [((12, 9, 72), 1, "exact", None), ((12, 9, 72), 1, "exact", s1), ((12, 9, 72), 2, "exact", s2),
+             ((7, 20, 100), 1, "fast", s1), ((12, 9, 72), 1, "fast", None), ((12, 9, 72), 1, "exact", s2)]
+    for n, (shape, ntr, variant, st) in enumerate(cases):
+        M.set_variant(M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST)
+        base, fs, inp = _stack(oracle, shape, ntr, dist=1)
+        d = {k: to_dev(v) for k, v in inp.items()}
+        torch.cuda.synchronize()
+        M.advect_scalar2D(d["f"], d["u"], d["w"], d["rho"], d["rhow"], d["flux"], d["adz"], stream=st)
+        torch.cuda.synchronize()
+        f, flux = to_host(d["f"]), to_host(d["flux"])
+        for t in range(ntr):
+            f_ref, flux_ref = oracle.advect(dict(base, f=fs[t].copy()), nthreads=4)
+            ft, flt = (f[..., t], flux[..., t]) if ntr > 1 else (f, flux)
+            if variant == "exact":
+                assert np.array_equal(ft, f_ref) and np.array_equal(flt, flux_ref), n
+            else:
+                assert max_abs(ft, f_ref) < 1e-12 and max_abs(flt, flux_ref) < 1e-12, n
+        if n == 2:
+            M.release_host_buffers()
+
+
+def test_direct_device_call_above_64_levels_still_there(oracle):
+    """MPDATA_DEVICE_CALL=direct (read once per process: a child): the k-marching kernel as up to round 5, same results"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import json, numpy as np, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import codesign_kernels_amd as M\n"
+        "from oracle import oracle as O\n"
+        "from util import run_hip\n"
+        "O.build_lib(); M.set_variant(M.VARIANT_EXACT)\n"
+        "inp = O.make_inputs(9, 32, 72, seed=5, dist=3)\n"
+        "f, fl = run_hip(M, inp)\n"
+        "fr, flr = O.advect(inp, nthreads=2)\n"
+        "print('RESULT ' + json.dumps({'ok': bool(np.array_equal(f, fr)) and bool(np.array_equal(fl, flr))}))\n"
+    ) % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPDATA_DEVICE_CALL="direct"), capture_output=True,
+                       text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])["ok"]
