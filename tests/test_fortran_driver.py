@@ -34,7 +34,8 @@ def test_driver_is_built_and_links_the_c_abi():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,dist,variant", [((100, 32, 28), 1, 0), ((48, 32, 58), 2, 0), ((64, 32, 28), 1, 1)])
+@pytest.mark.parametrize("shape,dist,variant", [((100, 32, 28), 1, 0), ((48, 32, 58), 2, 0), ((64, 32, 28), 1, 1),
+                                                ((40, 32, 72), 2, 0), ((33, 20, 100), 1, 1)])
 def test_driver_matches_oracle(oracle, tmp_path, shape, dist, variant):
     assert os.path.exists(EXE), "Fortran driver not built"
     ncrms, nx, nz = shape
@@ -79,7 +80,8 @@ def test_driver_matches_oracle(oracle, tmp_path, shape, dist, variant):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,dist,variant", [((100, 32, 28), 1, 0), ((101, 32, 28), 3, 0), ((64, 32, 28), 1, 1)])
+@pytest.mark.parametrize("shape,dist,variant", [((100, 32, 28), 1, 0), ((101, 32, 28), 3, 0), ((64, 32, 28), 1, 1),
+                                                ((64, 16, 72), 1, 0)])
 def test_single_precision_driver_matches_fp32_oracle(oracle, tmp_path, shape, dist, variant):
     """`make hip=1 single=1`: rp = fp32 (the reference's precision switch, :12), through
     mpdata_advect_scalar2d_f32 and the fp32 plan API; even ncrms -> packed kernels, odd ->
