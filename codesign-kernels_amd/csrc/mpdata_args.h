@@ -54,6 +54,8 @@ struct MpdataWmArgsT {
                            // (bit-identical flux: the finishing kernel adds them in the reference's order)
   unsigned long long* dbg; // diagnostic builds only (-DMPDWM_STAMPS): 8 words per wave (tools/wave_timeline.py); else null
   int nkw;                 // nz > 64 (kernel form LPS = 128): waves per instance and tracer, 1 + ceil((nz - 64) / 58); else 1
+  int lwt;                 // nz > 64: 16 / 32 = the last window of an instance is a 16- / 32-lane share of a wave (else 0)
+  int ksg;                 // ... and the instances per workgroup of that form (set by the launcher)
   int park_regs;           // EXACT only: 1 = park the limited vertical fluxes in REGISTERS (nx <= MPDATA_WM_NPK, one tracer per
                            // wave; wpark is then null: no park array, no finishing kernel)
 };

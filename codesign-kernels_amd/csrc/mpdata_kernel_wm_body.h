@@ -149,9 +149,14 @@ struct TileWm {
   // tile the column: 58 h + 4 .. 58 h + 61.  The other six levels are computed twice -- 5 % of the lanes at
   // nz = 72 ... 122 instead of a barrier and an LDS exchange at each of the four places of a column step where a
   // level takes something from its neighbour.  The layout is the one-instance-per-tile layout (chunk = nzm elements).
-  static constexpr bool KS = LPS == 128;
-  static constexpr int LW = KS ? 64 : LPS;      // lanes of a wave per instance
-  static constexpr int SLP = 64 / LW;           // instances per wave = per tile
+  // LPS = 128 + 16 / 128 + 32 = "KT", the LAST window of an instance when it needs no more than 16 / 32 levels (nz <= 74 /
+  // 90 with two windows): a wave then holds the last windows of 4 / 2 ADJACENT instances (= tiles), 16 / 32 lanes each,
+  // window start 58 (nkw - 1) -- 80 / 96 lanes per instance instead of 128 (mpdata_advect_wm_ks2_kernel).
+  static constexpr bool KS = LPS >= 128;
+  static constexpr bool KT = LPS > 128;
+  static constexpr int LW = KT ? LPS - 128 : (KS ? 64 : LPS);      // lanes of a wave per instance
+  static constexpr int SLP = KS ? 1 : 64 / LW;  // instances per tile (the layout; = per wave except KT)
+  static constexpr int TPV = KT ? 64 / LW : 1;  // tiles per wave
   static constexpr int WPB = WPB_;              // waves (= tiles) per workgroup; they never synchronise
   static constexpr int THREADS = 64 * WPB_;
   static constexpr int NZM_MAX = LPS - 1;       // lane k = nz is the ghost level (w = 0)
@@ -173,7 +178,7 @@ struct TileWm {
 #else
   static constexpr int MIN_WAVES_X = 2;
 #endif
-  static constexpr int MIN_WAVES = UWREF_ ? MIN_WAVES_X : (TPW_ == 2 ? 2 : (LW == 64 ? 3 : 4));
+  static constexpr int MIN_WAVES = UWREF_ ? MIN_WAVES_X : (TPW_ == 2 ? 2 : ((LW == 64 || KT) ? 3 : 4));
   static_assert(sizeof(R_) == 8, "8-byte elements (double, or two fp32 instances per lane)");
 };
 
@@ -199,14 +204,15 @@ struct TileWm {
 template <typename R, int LPS, int WPB, bool STREAM, int TPW = 1, bool UWREF = false, bool UWCONV = false, int NPK = 0>
 __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds, R* const my, const int wave,
                                         const unsigned tile, const unsigned tr, const unsigned ntr, const bool tile_ok,
-                                        const int kwave = 0) {
+                                        const int kwave = 0, const int ntl_in = 1) {
   using T = TileWm<R, LPS, WPB, TPW, UWREF>;
   static_assert(!UWCONV || UWREF, "UWCONV: the kernel that reads u, w from the reference layout");
   static_assert(TPW == 1 || (TPW == 2 && !STREAM), "two tracers per wave: batch form only");
   static_assert(!UWREF || (STREAM && TPW == 1), "u, w from the reference layout: one tracer per launch");
   static_assert(NPK == 0 || (TPW == 1 && !UWREF && NPK % 6 == 0), "register park: one tracer per wave, whole trips of six columns");
-  constexpr bool KS = T::KS;
+  constexpr bool KS = T::KS, KT = T::KT;
   constexpr int LW = T::LW;
+  constexpr bool WSEL = LW == 64 || KT;   // the ghost level's w = 0 by a select (no zero row of the LDS image to read it from)
   static_assert(!KS || (!STREAM && !UWREF), "nz > 64: the batch form of the data movement (one fetch instruction per array and pair)");
   using V = std::conditional_t<TPW == 1, R, Pair<R>>;   // a tracer-dependent quantity
   // PRE: the LDS inputs of a column step are read one step AHEAD of their use (software pipelining; the pair loop
@@ -279,27 +285,33 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   R* const f = a.f + (long long)tr * a.f_tstride + toff;
   const R* const u = a.u + toff;
   const R* const w = a.w + toff;
-  const R* const kc = a.kc + (long long)tile * (3 * chunk);
-  R* const flux = a.flux + (long long)tr * a.flux_tstride + (long long)tile * chunk;
+  // ---- lane -> (instance s, level k) -----------------------------------------
+  const int s_l = lane / LW;
+  // KT: the wave's tiles tile .. tile + ntl - 1 (ntl_in <= TPV of them, as the caller says); lane's tile = tile + s_l
+  [[maybe_unused]] const int ntl = tile_ok ? ntl_in : 0;
+  [[maybe_unused]] const bool tl_ok = !KT || s_l < ntl;
+  [[maybe_unused]] const int s_t = KT ? (tl_ok ? s_l : 0) : 0;   // tile of the lane's constants and flux (a lane without a tile: the first)
+  const R* const kc = a.kc + ((long long)tile + s_t) * (3 * chunk);
+  R* const flux = a.flux + (long long)tr * a.flux_tstride + ((long long)tile + s_t) * chunk;
   // second tracer of the wave (TPW = 2); if it does not exist (odd ntracers) it is addressed through
   // an EMPTY buffer range: its fetches deliver zeros, its stores are dropped
   const bool has1 = TPW == 2 && tr + 1 < ntr;
   R* const f1 = has1 ? f + a.f_tstride : f;
   R* const flux1 = has1 ? flux + a.flux_tstride : flux;
 
-  // ---- lane -> (instance s, level k) -----------------------------------------
-  const int s_l = lane / LW;
   // KS: the wave's first level - 1.  58 kwave, but never past the (even) start from which the wave still reaches nz
+  // (KT: 58 kwave: the host chooses this form only where 58 (nkw - 1) + LW >= nz)
   int koff = 0;
-  if constexpr (KS) koff = min(58 * kwave, max(0, (nz - 64 + 1) & ~1));
+  if constexpr (KT) koff = 58 * kwave;
+  else if constexpr (KS) koff = min(58 * kwave, max(0, (nz - 64 + 1) & ~1));
   const int kk = lane % LW + koff;         // k - 1
   const int k = kk + 1;
   const bool lvl_ok = k <= nzm;            // real level (else ghost / dead lane)
   const int kl = lvl_ok ? kk : nzm - 1;    // level index whose data the lane reads
-  const int pos = s_l * nzm + kl;          // element of the chunk
+  const int pos = (KS ? 0 : s_l * nzm) + kl;          // element of the chunk
   // the levels whose results this wave stores (KS: the part of its 64 that is outside the cone of its artificial ends)
   bool out_ok = lvl_ok;
-  if constexpr (KS) out_ok = lvl_ok && (kwave == 0 || k >= 58 * kwave + 4) && (kwave + 1 == a.nkw || k <= 58 * kwave + 61);
+  if constexpr (KS) out_ok = lvl_ok && tl_ok && (kwave == 0 || k >= 58 * kwave + 4) && (kwave + 1 == a.nkw || k <= 58 * kwave + 61);
 
   // per-lane constants (:552, :553, :565, :569): the loads go out here, the arithmetic on them
   // follows the DMA prologue below (a wave's first column fetch must not queue behind a
@@ -323,9 +335,11 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   //      level below ever takes from it (www(:,:,:,nz) = 0, :511).
   // (KS: the LDS image of a column holds the wave's 64 levels; the first and the last lane of a wave that does not hold
   //  level 1 / level nzm read themselves as their neighbour: they are inside the cone of the wave's artificial end)
-  const R* const p_own = my + ((LW == 64 || lvl_ok) ? pos - koff : 63);
-  const R* const p_dn = my + (s_l * nzm + max((kl > 0 ? kl - 1 : 0) - koff, 0));
-  const R* const p_up = my + (s_l * nzm + min((kl + 1 < nzm ? kl + 1 : nzm - 1) - koff, KS ? 63 : 1 << 30));
+  // (KT: the image of a column = the windows of the wave's tiles, LW rows each)
+  constexpr int IST = KT ? LW : 0;   // rows between the images of two tiles of a wave
+  const R* const p_own = my + ((WSEL || lvl_ok) ? (KT ? s_l * IST + kl - koff : pos - koff) : 63);
+  const R* const p_dn = my + ((KT ? s_l * IST : (KS ? 0 : s_l * nzm)) + max((kl > 0 ? kl - 1 : 0) - koff, 0));
+  const R* const p_up = my + ((KT ? s_l * IST : (KS ? 0 : s_l * nzm)) + min((kl + 1 < nzm ? kl + 1 : nzm - 1) - koff, KS ? LW - 1 : 1 << 30));
 
   // ---- global addressing: one descriptor per array, based at the wave's tile (32-bit offsets
   //      inside a tile, arrays of any size).  Element e of column c of the tile lives at
@@ -335,13 +349,16 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   const unsigned mainB = chunkB / 128u * 128u, remB = chunkB - mainB;
   const unsigned remBase = (unsigned)ncol * mainB;
   const long long tileB = (long long)ncol * chunkB;
+  // KT: the wave's descriptors span its ntl tiles (a.tile_elems apart); a lane adds its tile's offset
+  [[maybe_unused]] const unsigned tstrB = (unsigned)(a.tile_elems * RB);
+  const long long spanB = KT ? (ntl > 0 ? (long long)(ntl - 1) * tstrB + tileB : 0) : tileB;
   // (!tile_ok -- the u, w-ring form and the nz > 64 form, whose workgroups synchronise: a wave beyond the last tile stays
   //  and works on EMPTY ranges: its fetches deliver zeros, its stores are dropped)
-  const __amdgpu_buffer_rsrc_t rsf = v2::make_rsrc(f, !tile_ok ? 0 : tileB);
-  const __amdgpu_buffer_rsrc_t rsf1 = v2::make_rsrc(f1, (has1 && tile_ok) ? tileB : 0);
+  const __amdgpu_buffer_rsrc_t rsf = v2::make_rsrc(f, !tile_ok ? 0 : spanB);
+  const __amdgpu_buffer_rsrc_t rsf1 = v2::make_rsrc(f1, (has1 && tile_ok) ? spanB : 0);
   // (UWREF: u, w of the plan are not read; UWCONV writes them)
-  const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : (tile_ok ? tileB : 0));
-  const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : (tile_ok ? tileB : 0));
+  const __amdgpu_buffer_rsrc_t rsu = v2::make_rsrc(u, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : (tile_ok ? spanB : 0));
+  const __amdgpu_buffer_rsrc_t rsw = v2::make_rsrc(w, UWREF ? ((UWCONV && tile_ok) ? tileB : 0) : (tile_ok ? spanB : 0));
   // EXACT with a park array (a.wpark != null): bit-identical flux.  The reference adds the limited vertical fluxes
   // ONE BY ONE onto the finished upwind sum (:545, :624), and the first of them exists 30 columns before that sum is
   // complete: every lane parks its nx limited fluxes in [tracer][tile][column 1..nx][lane] (one 512-byte row per wave
@@ -413,11 +430,14 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   // DMA source offsets of a pair instruction: lane L < 32 fetches bytes 16L.. of the even column,
   // lane L >= 32 bytes 16(L-32).. of the odd one (the LDS image keeps the two columns 512 B apart);
   // the lanes of a column's main part in the one instruction, those of its remainder in the other
-  const unsigned in_col = (unsigned)((lane & 31) * 16 + koff * RB);   // (KS: the wave's 512 bytes of the column start at level koff + 1)
+  // (KT: the 32 lanes of a column = LW / 2 pieces of each of the wave's tiles: the image keeps the windows LW rows apart)
+  constexpr int PPT = KT ? LW / 2 : 32;   // 16-byte pieces of a column per tile
+  const unsigned in_col = (unsigned)(((lane & 31) % PPT) * 16 + koff * RB);   // (KS: the wave's 512 bytes of the column start at level koff + 1)
+  [[maybe_unused]] const unsigned dtB = KT ? (unsigned)((lane & 31) / PPT) * tstrB : 0u;   // the tile the lane FETCHES for
   const unsigned hi = lane >= 32 ? 1u : 0u;
   const bool lane_main = in_col < mainB;
-  const unsigned vA = lane_main ? in_col + hi * mainB : OOB;
-  const unsigned vB = (in_col >= mainB && in_col < chunkB) ? remBase + (in_col - mainB) + hi * remB : OOB;
+  const unsigned vA = lane_main ? in_col + hi * mainB + dtB : OOB;
+  const unsigned vB = (in_col >= mainB && in_col < chunkB) ? remBase + (in_col - mainB) + hi * remB + dtB : OOB;
   // only the even / only the odd column of a pair: the other half of the lanes out of range
   auto halves = [&](const unsigned v, const bool e, const bool o) __attribute__((always_inline)) {
     if (e && o) return v;
@@ -454,7 +474,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
   };
   // store offset of column c = q - 1 of the step about to run; the march starts at q = -2, behind one
   // empty flush of the deferred-store slot, which advances the offset as well
-  unsigned scur = out_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) - (PRE ? 3u : 4u) * cstride : OOB;
+  unsigned scur = out_ok ? (posB < mainB ? posB : remBase + (posB - mainB)) + (KT ? (unsigned)s_l * tstrB : 0u) - (PRE ? 3u : 4u) * cstride : OOB;
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   // pair P of all three arrays into its ring slot.  e*/o*: which columns of the pair exist for
@@ -628,7 +648,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
     r.f0q = ldv(p_own + LO);
     r.uq = p_own[LO + T::UO];
     r.wq = p_own[LO + T::WO];
-    if constexpr (LW == 64) r.wq = lvl_ok ? r.wq : R(0);
+    if constexpr (WSEL) r.wq = lvl_ok ? r.wq : R(0);
     r.f0d = ldv(p_dn + LO);
     r.f0u = ldv(p_up + LO);
     r.ud = p_dn[LO + T::UO];
@@ -668,7 +688,7 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
       f0q = ldv(p_own + LO);
       uq = p_own[LO + T::UO];
       wq = p_own[LO + T::WO];
-      if constexpr (LW == 64) wq = lvl_ok ? wq : R(0);
+      if constexpr (WSEL) wq = lvl_ok ? wq : R(0);
     } else {
       f0q = in.f0q; uq = in.uq; wq = in.wq;
     }
@@ -1187,6 +1207,54 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
     if (a.reverse) tile = (unsigned)a.ntiles - 1u - tile;
   }
   wm_body<R, LPS, WPB, STREAM, TPW, UWREF, UWCONV, NPK>(a, lds, lds + wave * (T::NS * T::SLOT), wave, tile, tr, ntr, tile_ok, kwave);
+}
+
+// nz > 64 with a SHORT last window (round 5): the last of an instance's two windows needs nz - 58 levels; where that is at most
+// LWT = 16 / 32 (nz <= 74 / 90), "tail" waves hold the last windows of 64 / LWT adjacent instances each (body form
+// LPS = 128 + LWT) beside the instances' full-width waves.  A workgroup = a.ksg instances = ksg full-width waves +
+// ceil(ksg LWT / 64) tail waves, which meet in the barrier of the column pairs like the waves of the plain form.  ksg is
+// 3 at LWT = 16 (3 + 1 = FOUR waves: 85 lanes per instance instead of 128) and 2 at LWT = 32 (2 + 1 waves: 96 lanes).
+// With 4 + 1 waves at LWT = 16 only ONE workgroup was ever resident on a CU (measured: 4.8 waves per CU on average --
+// the dispatcher places a workgroup's waves round-robin over the SIMDs from the first one, and a second 2-1-1-1 does not
+// fit beside the first at 3 waves per SIMD) and the form was no faster than the plain one at 38 % fewer instructions;
+// 5 + 3 = eight waves at LWT = 32 (one workgroup per CU) lost against 2 + 1 (which leaves the fourth SIMD idle).
+// Three waves per SIMD (134 registers, FAST): at four (128 registers, 24 bytes of scratch) 3 % slower.
+// LDS: a ring per wave, sized by the launch.
+template <typename R, int LWT, int TPW = 1, int NPK = 0>
+__global__ void __launch_bounds__(64 * 4, ((TPW == 2 || NPK > 0) ? 2 : 3))
+mpdata_advect_wm_ks2_kernel(const MpdataWmArgsT<R> a) {
+  using TM = TileWm<R, 128, 4, TPW, false>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  R* const lds = reinterpret_cast<R*>(lds_raw);
+  constexpr unsigned TP = 64 / LWT;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntr = (unsigned)a.ntracers, G = (unsigned)a.ksg;
+  const unsigned ngrp = ((unsigned)a.ntiles + G - 1) / G;
+  unsigned grp, tr;
+  if (ntr == 1 && TPW == 1) {
+    grp = blockIdx.x;
+    tr = 0;
+  } else {   // (as the plain form: the workgroups an XCD receives walk through the tracer slots of one group after the other)
+    const unsigned nxcd = 8, ntw = (ntr + TPW - 1) / TPW;
+    const unsigned v = blockIdx.x / nxcd;
+    tr = (v % ntw) * TPW;
+    grp = (v / ntw) * nxcd + blockIdx.x % nxcd;
+  }
+  if (grp >= ngrp) return;   // (the whole workgroup: before any barrier)
+  if (a.reverse) grp = ngrp - 1u - grp;
+  R* const my = lds + wave * (TM::NS * TM::SLOT);
+  if ((unsigned)wave < G) {
+    unsigned tile = grp * G + (unsigned)wave;
+    const bool tile_ok = tile < (unsigned)a.ntiles;
+    if (!tile_ok) tile = (unsigned)a.ntiles - 1u;
+    wm_body<R, 128, 4, false, TPW, false, false, NPK>(a, lds, my, wave, tile, tr, ntr, tile_ok, 0);
+  } else {
+    const unsigned first = ((unsigned)wave - G) * TP;   // first instance of the group in this tail wave
+    unsigned tile = grp * G + first;
+    const int ntl = max(0, min(min((int)TP, (int)G - (int)first), a.ntiles - (int)tile));
+    if (ntl == 0) tile = (unsigned)a.ntiles - 1u;
+    wm_body<R, 128 + LWT, 4, false, TPW, false, false, NPK>(a, lds, my, wave, tile, tr, ntr, ntl > 0, 1, ntl);
+  }
 }
 
 // Tracer batches with an ODD number of tracers, one launch (round 5): the waves of a tile are its tracer pairs

@@ -183,8 +183,20 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
 // data movement; EXACT with the register park (the caller makes sure that nx <= MPDATA_WM_NPK or that no flux order
 // is asked for)
 template <typename R>
+static void launch_wm_ks2(const MpdataWmArgsT<R>& a, void* stream);
+template <typename R>
 static void launch_wm_ks(const MpdataWmArgsT<R>& a, void* stream) {
   constexpr int WPB = MPDWM_WPB;
+  // a short last window: the tail form (mpdata_advect_wm_ks2_kernel); not with the 66-column register park (EXACT,
+  // nx 37 .. 66: the tail wave's per-lane tile offsets are three registers more than the 256 there are)
+  bool tail = a.lwt != 0;
+#ifndef MPDATA_FAST_DIV
+  if (a.park_regs && a.nx > MPDATA_WM_NPK) tail = false;
+#endif
+  if (tail) {
+    launch_wm_ks2<R>(a, stream);
+    return;
+  }
   // a workgroup = the nkw waves of each of its ipw instances (they synchronise once per column pair, see the kernel)
   const int ipw = WPB / a.nkw > 0 ? WPB / a.nkw : 1;
   const unsigned threads = 64u * (unsigned)(ipw * a.nkw);
@@ -215,6 +227,39 @@ static void launch_wm_ks(const MpdataWmArgsT<R>& a, void* stream) {
 #endif
   hipLaunchKernelGGL((wm::mpdata_advect_wm_kernel<R, 128, WPB, false, 1>), dim3(blocks_for(a.ntracers)), dim3(threads), 0,
                      (hipStream_t)stream, a);
+}
+// nz > 64 with a short last window (a.lwt = 16 / 32): workgroups of G instances = G full-width waves and
+// ceil(G lwt / 64) tail waves; a ring per wave in dynamic LDS
+template <typename R>
+static void launch_wm_ks2(const MpdataWmArgsT<R>& a_in, void* stream) {
+  MpdataWmArgsT<R> a = a_in;
+  // instances per workgroup (see the kernel): 3 + 1 waves at lwt = 16, 2 + 1 at lwt = 32
+  const int G = a.lwt == 16 ? 3 : 2, TP = 64 / a.lwt, waves = G + (G + TP - 1) / TP;
+  a.ksg = G;
+  const unsigned threads = 64u * (unsigned)waves;
+  const long long ngrp = ((long long)a.ntiles + G - 1) / G;
+  auto blocks_for = [&](const int slots) -> unsigned {
+    if (slots == 1) return (unsigned)ngrp;
+    return (unsigned)(8 * ((ngrp + 7) / 8) * slots);
+  };
+  auto lds_for = [&](const int tpw) -> unsigned { return (unsigned)(waves * 3 * (2 + tpw) * 128 * 8); };
+#define KS2_LAUNCH(TPW_, NPK_, SLOTS_)                                                                                   \
+  {                                                                                                                      \
+    if (a.lwt == 16)                                                                                                     \
+      hipLaunchKernelGGL((wm::mpdata_advect_wm_ks2_kernel<R, 16, TPW_, NPK_>), dim3(blocks_for(SLOTS_)), dim3(threads),  \
+                         lds_for(TPW_), (hipStream_t)stream, a);                                                         \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((wm::mpdata_advect_wm_ks2_kernel<R, 32, TPW_, NPK_>), dim3(blocks_for(SLOTS_)), dim3(threads),  \
+                         lds_for(TPW_), (hipStream_t)stream, a);                                                         \
+    return;                                                                                                              \
+  }
+#ifndef MPDATA_FAST_DIV
+  if (a.park_regs && a.nx <= MPDATA_WM_NPK) KS2_LAUNCH(1, MPDATA_WM_NPK, a.ntracers)
+#else
+  if (a.ntracers >= 2) KS2_LAUNCH(2, 0, (a.ntracers + 1) / 2)
+#endif
+  KS2_LAUNCH(1, 0, a.ntracers)
+#undef KS2_LAUNCH
 }
 bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags) {
   if (wpb != MPDWM_WPB) return false;
@@ -271,6 +316,7 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   a.wpark = reinterpret_cast<v2::f32x2*>(a8.wpark);
   a.park_regs = a8.park_regs;
   a.nkw = a8.nkw;
+  a.lwt = a8.lwt;
   if (lps == 128) {
     launch_wm_ks<v2::f32x2>(a, stream);
     return true;

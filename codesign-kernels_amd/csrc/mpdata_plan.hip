@@ -124,6 +124,14 @@ MpdataLayoutJob wm_job(const mpdata_plan* p, int which, void* ref, int first_tra
 #define MPDATA_WM_NZ_MAX 127
 int wm_lps_for(int nz) { return nz <= 8 ? 8 : nz <= 16 ? 16 : nz <= 32 ? 32 : nz <= 64 ? 64 : nz <= MPDATA_WM_NZ_MAX ? 128 : 0; }
 int wm_nkw_for(int nz) { return nz <= 64 ? 1 : 1 + (nz - 64 + 57) / 58; }
+// nz > 64: lanes of the last window where it is a share of a wave (16: the window needs <= 16 levels, 32: <= 32; else 0 = a
+// wave of its own); MPDATA_KS_TAIL=0: never (A/B)
+int wm_lwt_for(int nz) {
+  static const bool off = getenv("MPDATA_KS_TAIL") && !strcmp(getenv("MPDATA_KS_TAIL"), "0");
+  if (nz <= 64 || off || wm_nkw_for(nz) != 2) return 0;   // (three windows: a 9-wave workgroup would cap the two-waves-per-SIMD forms' registers)
+  const int need = nz - 58 * (wm_nkw_for(nz) - 1);
+  return need <= 16 ? 16 : need <= 32 ? 32 : 0;
+}
 
 int plan_check(const mpdata_plan* p, int eb) {
   if (!p) return set_err(MPDATA_EINVAL, "null plan");
@@ -500,6 +508,7 @@ static int plan_launch(mpdata_plan* p, int first, int count, const void* u_ref =
       }
     }
     a.wpark = (p->wpark && !a.park_regs) ? (double*)p->wpark + (long long)first * p->ntiles * a.nkw * ((long long)p->nx * 64) : nullptr;
+    a.lwt = (a.wpark || u_ref) ? 0 : wm_lwt_for(p->nz);   // (the park array is laid out for whole-wave windows)
     const bool fast = p->variant == MPDATA_VARIANT_FAST;
     if (u_ref) {
       a.reverse = 0;

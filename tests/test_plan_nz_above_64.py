@@ -16,8 +16,11 @@ pytestmark = pytest.mark.gpu
 
 # nz: the first size of the form (65), seams at every parity (koff of the last wave = the even number >= nz - 64),
 # the largest two-wave size (122), three waves (123 ... 127 = the largest the layout kernels take)
+# (nz <= 74 / <= 90: the last window is a 16- / 32-lane share of a wave that holds those of 4 / 2 instances -- workgroups
+#  of 3 / 2 instances: ncrms at every remainder; 74 | 75 and 90 | 91 are the seams between the forms)
 SHAPES = [(9, 32, 72), (4, 5, 65), (3, 7, 66), (5, 12, 67), (6, 3, 100), (3, 7, 121), (2, 9, 122), (3, 4, 123),
-          (5, 12, 127), (130, 32, 72), (67, 33, 90)]
+          (5, 12, 127), (130, 32, 72), (67, 33, 90), (7, 9, 74), (5, 11, 75), (1, 4, 70), (2, 6, 80), (11, 5, 91),
+          (10, 8, 89), (3, 40, 73), (131, 13, 81)]
 
 
 @pytest.fixture(autouse=True)
@@ -63,7 +66,8 @@ def test_shapes_above_64_levels(mpdata, oracle, shape, variant, dist):
     assert np.array_equal(flux[:, -1], inp["flux"][:, -1])
 
 
-@pytest.mark.parametrize("shape,ntr", [((9, 32, 72), 3), ((21, 7, 100), 2), ((4, 12, 125), 5)])
+@pytest.mark.parametrize("shape,ntr", [((9, 32, 72), 3), ((21, 7, 100), 2), ((4, 12, 125), 5), ((7, 10, 80), 4),
+                                       ((5, 9, 66), 5), ((20, 6, 74), 2)])
 @pytest.mark.parametrize("variant", ["exact", "fast"])
 def test_tracer_batches_above_64_levels(mpdata, oracle, shape, ntr, variant):
     M = mpdata
@@ -212,7 +216,7 @@ def test_4096_instances_of_72_levels_and_its_rate(mpdata, oracle):
     assert frac >= 0.40, (ms, frac)
 
 
-@pytest.mark.parametrize("shape", [(10, 9, 72), (4, 5, 65), (6, 12, 127), (130, 32, 72)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(10, 9, 72), (4, 5, 65), (6, 12, 127), (130, 32, 72), (10, 7, 80), (14, 5, 90)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("variant", ["exact", "fast"])
 def test_fp32_plans_above_64_levels(mpdata, oracle, shape, variant):
     """fp32 plans with an even ncrms (two adjacent instances per lane) at nz > 64: the same several-waves-per-instance form
