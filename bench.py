@@ -382,7 +382,7 @@ def inject_failure(name, phase):
 TAIL_LAST = ("cpu_baseline", "twice_the_instances", "two_launches_in_flight", "reference_layout_device_call",
              "step_with_fresh_uw", "exact_variant", "tracer_batched", "scatter_gather")
 HEAD_AFTER_HEADLINE = ("layout_conversion", "biharmonic_wk", "high_order_flux", "end_to_end_host_call", "fp32",
-                       "consecutive_tracers_shared_uw")
+                       "consecutive_tracers_shared_uw", "levels_above_64")
 
 
 def ordered_for_the_tail(d):
@@ -1069,6 +1069,22 @@ def main():
             "ms_per_step": dtm / xsteps * 1e3,
             "roofline": roofline_block(M.algorithmic_bytes(n2, nx, nz, 1), kms8)}
 
+    # nz > 64 (the plan kernel's window form; 72 levels: the last window of an instance is a share of a tail wave), the
+    # headline protocol at about the headline's cell count
+    def b_nz72():
+        n72, z72 = max(2, (3 * n_loc // 8) & ~1), 72
+        xsteps = min(steps, 16)
+        shared72, _, sh72 = make_shared(M, torch, dev, n72, n72 * world, rank * n72, nx, z72, args.dist, tdt)
+        dt72, kms72, info72 = bench_plan(M, torch, dist, world, dev, shared72, sh72["f"], n72, n72 * world, rank * n72, nx, z72, 1,
+                                         xsteps, SIDE_WARMUP, args.dist, npdt, tdt, 0.5 * mem_frac)
+        del shared72
+        return dt72, lambda dtm: {
+            "workload": f"the headline protocol (cold, {info72['field_sets']} sets) at ncrms={n72}/GPU nx={nx} nz={z72} fp64, 1 tracer: "
+                        "several waves per instance",
+            "value": n72 * nx * (z72 - 1) * xsteps / dtm, "unit": "cell-updates/s", "steps": xsteps,
+            "ms_per_step": dtm / xsteps * 1e3,
+            "roofline": roofline_block(M.algorithmic_bytes(n72, nx, z72, 1), kms72)}
+
     # The headline protocol with TWO launches in flight: consecutive steps are independent (a plan of its own each), so a
     # caller that has more than one batch of CRM instances to advect can alternate between two streams -- the drain of one
     # launch (its last wave round ends spread over ~40 us) then overlaps the ramp of the next.  NOT the headline: there a
@@ -1302,6 +1318,8 @@ def main():
             side("twice_the_instances", b_x2)
         if not args.no_x2 and one and not f32 and not args.shared_uw:
             side("two_launches_in_flight", b_two_in_flight)
+        if not args.no_x2 and one and not f32 and not args.shared_uw and nz <= 64:
+            side("levels_above_64", b_nz72)
         if not args.no_batched and one:
             side("tracer_batched", b_batched)
         if not args.no_reflayout and one:

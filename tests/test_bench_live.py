@@ -41,7 +41,7 @@ def test_live_line_meets_the_contract():
     early = [ln for ln in res.stderr.splitlines() if ln.startswith("BENCH_HEADLINE {")]
     assert len(early) == 1 and json.loads(early[0].split(" ", 1)[1])["value"] == d["value"]
     for blk in ("step_with_fresh_uw", "twice_the_instances", "tracer_batched", "reference_layout_device_call",
-                "exact_variant"):
+                "exact_variant", "levels_above_64"):
         assert d[blk]["value"] > 0 and 0 < d[blk]["roofline"]["frac"] < 1, blk
     tf = d["two_launches_in_flight"]   # throughput only: no per-kernel duration is claimed when two kernels share the chip
     assert tf["value"] > 0 and "roofline" not in tf and 0 < tf["frac_of_8TBs_throughput"] < 1

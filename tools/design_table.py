@@ -20,6 +20,8 @@ tbl = ("| workload | ms / step | frac of 8 TB/s | Gcu/s |\n|---|---|---|---|\n"
        "| `mpdata_plan_run_uw` | %s | %s | %s |\n" % row(d["step_with_fresh_uw"]) +
        "| reference-layout device call | %s | %s | %s |\n" % row(d["reference_layout_device_call"]) +
        "| fp32 plan | %s | %s | %s |\n" % row(d["fp32"]) +
+       ("| 72 levels (%s) | %s | %s | %s |\n" % ((d["levels_above_64"]["workload"].split(" at ")[1].split(" fp64")[0],) + row(d["levels_above_64"]))
+        if "levels_above_64" in d else "") +
        "| EXACT: one tracer / 25 tracers / device call | %.3f / %.2f / %.3f | %.3f / %.3f / %.3f | %.1f / %.1f / %.1f |\n" % (
            ex["ms_per_step"], ex["tracer_batched"]["ms_per_step"], ex["reference_layout_device_call"]["ms_per_step"],
            ex["roofline"]["frac"], ex["tracer_batched"]["roofline"]["frac"], ex["reference_layout_device_call"]["roofline"]["frac"],
