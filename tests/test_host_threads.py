@@ -18,8 +18,10 @@ def test_threads_with_their_own_plans_and_streams(mpdata, oracle):
     M = mpdata
     M.set_variant(M.VARIANT_EXACT)
     M.set_wm_flags(0)
-    shapes = [(96, 32, 28), (50, 17, 12), (64, 32, 58), (33, 9, 20)]
-    nthreads, rounds = 4, 6
+    # (72 levels: several waves per instance in the plan, and the device call goes through a plan the library keeps for
+    #  the calling THREAD -- freed when the thread ends)
+    shapes = [(96, 32, 28), (50, 17, 12), (64, 32, 58), (33, 9, 20), (34, 9, 72)]
+    nthreads, rounds = 5, 6
     cases = []
     for t, (ncrms, nx, nz) in enumerate(shapes):
         inp = oracle.make_inputs(ncrms, nx, nz, seed=4100 + t, dist=1)
