@@ -26,7 +26,7 @@ tbl = ("| workload | ms / step | frac of 8 TB/s | Gcu/s |\n|---|---|---|---|\n"
            ex["ms_per_step"], ex["tracer_batched"]["ms_per_step"], ex["reference_layout_device_call"]["ms_per_step"],
            ex["roofline"]["frac"], ex["tracer_batched"]["roofline"]["frac"], ex["reference_layout_device_call"]["roofline"]["frac"],
            ex["value"] / 1e9, ex["tracer_batched"]["value"] / 1e9, ex["reference_layout_device_call"]["value"] / 1e9) +
-       "| two launches in flight (two streams, independent plans; throughput only, NOT the headline) | %.4f | %.3f | %.1f |\n" % (
+       "| two launches in flight (two streams; throughput only, NOT the headline) | %.4f | %.3f | %.1f |\n" % (
            tf["ms_per_step"], tf["frac_of_8TBs_throughput"], tf["value"] / 1e9) +
        "| reference executable, 1 host core | — | — | %.3f |" % (d["cpu_baseline"]["value"] / 1e9))
 path = os.path.join(root, "DESIGN.md")
@@ -39,8 +39,9 @@ j = s.index("\n\n", i)
 r = d["roofline"]
 s = s[:i] + ("Round-5 record (builder's box, the FINAL library, driver arguments `--gpus 1 --steps 20 --warmup 5`;\n"
              "profiles/%s_bench_driver.json): the timed average sits %.1f %% %s the per-launch median, `frac_of_measured_ceiling` %.3f;\n"
-             "kernel trace and PMC passes: %s_kernel_stats.csv, %s_pmc_summary.json (profiles/README.md).  The boxes of the pool differ\n"
-             "by 2–3 %% on one binary." % (tag, abs(r["avg_over_median"] - 1) * 100, "above" if r["avg_over_median"] > 1 else "below",
-                                          r["frac_of_measured_ceiling"], tag, tag)) + s[j:]
+             "kernel trace and PMC passes: %s_kernel_stats.csv, %s_pmc_summary.json.  Boxes differ by 2–3 %% on one binary.  Other\n"
+             "shapes (%s_shape_sweep.txt; nx 32 … 256, nz 28 … 110): FAST 0.62–0.68, nz = 125 0.54." % (
+                 tag, abs(r["avg_over_median"] - 1) * 100, "above" if r["avg_over_median"] > 1 else "below",
+                 r["frac_of_measured_ceiling"], tag, tag, tag)) + s[j:]
 open(path, "w").write(s)
 print(tbl)

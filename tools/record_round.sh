@@ -5,6 +5,7 @@
 #   gpurun_out/<tag>_final/fortran_driver.txt  the Fortran driver: host mode (1 tracer), device mode (25 tracers),
 #                                              ngpus = 1 through the multi-GPU path, 2 shards on one device
 #   gpurun_out/<tag>_final/fortran_side_drivers.txt  bwk_driver and nested_hip (second / third kernel)
+#   gpurun_out/<tag>_final/shape_sweep.txt, ab_kstail.txt   tools/shape_sweep.sh, tools/ab_kstail.sh
 #   gpurun_out/prof_<tag>/                      tools/profile_round.sh (rocprofv3 kernel trace + PMC passes)
 # then here: python tools/pmc_summary.py <tag>; copy the records into profiles/.
 TAG=${1:-r05}
@@ -24,6 +25,8 @@ F=codesign-kernels_amd/fortran/advect
   MPDATA_MULTI_DEVICES=0,0 $F 131072 32 28 1 1 - - 25 2 device
   echo "== ngpus = 2 on ONE device, host mode (direct transport), 2 tracers, ncrms = 65536"
   MPDATA_MULTI_DEVICES=0,0 $F 65536 32 28 1 1 - - 2 2 host
+  echo "== 72 levels (several waves per instance; the device call goes through the calling thread's plan), device mode, FAST:  $F 24576 32 72 1 1 - - 1 1 device"
+  $F 24576 32 72 1 1 - - 1 1 device
   echo "== namelist: configs[3] through a namelist file"
   printf "&advect_nml ncrms=65536, nx=32, nz=28, dist=1, variant=1, ntracers=25, ngpus=1, mode='device' /\n" > $OUT/case.nml
   $F $OUT/case.nml
@@ -39,5 +42,8 @@ D=codesign-kernels_amd/fortran
   echo "== $D/nested_hip nested32.nml 1   (a mesh 32 x the namelist's, random connectivity, FAST)"; $D/nested_hip $OUT/nested32.nml 1
 } > $OUT/fortran_side_drivers.txt 2>&1
 echo "side drivers rc=$?"
+# the plan kernel over the CRM shapes in use (cold, one tracer), and the tail form of nz 65 .. 90 against whole-wave windows
+bash tools/shape_sweep.sh fast > $OUT/shape_sweep.txt 2>&1; bash tools/shape_sweep.sh exact | sed 's/^== /== EXACT /' >> $OUT/shape_sweep.txt 2>&1; echo "shape sweep rc=$?"
+bash tools/ab_kstail.sh > $OUT/ab_kstail.txt 2>&1; echo "kstail rc=$?"
 # the profile passes take ~10 minutes: a gpurun call of their own (PROFILE=0 skips them here)
 if [ "${PROFILE:-1}" = 1 ]; then timeout -k 10 1000 bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1; echo "profile rc=$?"; fi
