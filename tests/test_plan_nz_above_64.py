@@ -404,3 +404,33 @@ def test_direct_device_call_above_64_levels_still_there(oracle):
                        text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])["ok"]
+
+
+def test_arrays_larger_than_4GiB_at_72_levels(mpdata, oracle):
+    """ncrms = 210000 at 32 x 72: f, u, w 4.4-4.5 GB each -- the plan (descriptors per wave: tiles of the tail waves are up to
+    three tile strides apart, still far below 4 GiB), the layout kernels' import / export at nz > 64, and the device call
+    through the calling thread's plan: sampled blocks against the oracle, the output contract on the whole arrays."""
+    import torch
+    from test_plan_wavemajor import _full_size_check
+    M = mpdata
+    ncrms, nx, nz = 210000, 32, 72
+    blocks = ((0, 40), (99999, 37), (ncrms - 21, 21))
+    _full_size_check(M, oracle, M.VARIANT_EXACT, ncrms, nx, nz, 1, blocks)
+    # the same problem as ONE call on reference-layout device arrays
+    M.set_variant(M.VARIANT_EXACT)
+    sh = M.shapes(ncrms, nx, nz, 1)
+    d = {k: torch.empty(s, dtype=torch.float64, device="cuda:0") for k, s in sh.items()}
+    for k in ("f", "u", "w", "rho", "rhow", "adz", "flux"):
+        M.fill_synthetic(d[k], k, 100, oracle.DIST_CONDITIONED)
+    top = d["flux"][nz - 1].clone()
+    M.advect_scalar2D(d["f"], d["u"], d["w"], d["rho"], d["rhow"], d["flux"], d["adz"])
+    torch.cuda.synchronize()
+    assert torch.equal(d["flux"][nz - 1], top) and bool(torch.isfinite(d["f"]).all())
+    for s0, n in blocks:
+        inp = oracle.make_inputs(n, nx, nz, seed=100, dist=oracle.DIST_CONDITIONED, ncrms_global=ncrms, sl0=s0)
+        f_ref, flux_ref = oracle.advect(inp)
+        assert np.array_equal(to_host(d["f"][..., s0:s0 + n]), f_ref), s0
+        assert np.array_equal(to_host(d["flux"][..., s0:s0 + n]), flux_ref), s0
+    del d
+    M.release_host_buffers()
+    torch.cuda.empty_cache()
