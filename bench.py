@@ -826,6 +826,8 @@ def main():
         sys.exit(self_launch(args.gpus))
     ALIGNED = args.aligned
     PREWARM_MS, PREWARM_MIN_MS = args.prewarm_ms, min(args.prewarm_min_ms, args.prewarm_ms)
+    # (a rank started by someone else's launcher: the same default as self_launch gives its children, before HIP loads)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     life = Lifeline()
     import numpy as np
     import torch
