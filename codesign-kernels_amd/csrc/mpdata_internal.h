@@ -78,7 +78,7 @@ bool exact_flux_in_order();
 bool exact_flux_in_regs();
 
 // one call on reference-layout device arrays (x-march / k-march kernels); var: MPDATA_VARIANT_* (< 0: the global one);
-// staged: 65 <= nz <= 127 may go through the calling thread's wave-major plan (staged_device_call below)
+// staged: 65 <= nz <= 238 may go through the calling thread's wave-major plan (staged_device_call below)
 template <typename R>
 int advect_device(int64_t ncrms, int nx, int nz, int ntracers, R* f, const R* u, const R* w, const R* rho, const R* rhow,
                   const R* adz, R* flux, void* stream, int var = -1, bool staged = true);
@@ -89,7 +89,7 @@ extern template int advect_device<float>(int64_t, int, int, int, float*, const f
 
 // frees the calling thread's park buffers of the EXACT device calls (mpdata_core.hip: park_buffer)
 void park_buffers_release();
-// calls on reference-layout device arrays at 65 <= nz <= 127 through a wave-major plan kept per host thread
+// calls on reference-layout device arrays at 65 <= nz <= 238 through a wave-major plan kept per host thread
 // (mpdata_plan.hip); eb = bytes per real
 bool staged_call_applies(int64_t ncrms, int nz, int eb);
 int staged_device_call(int eb, int64_t ncrms, int nx, int nz, int ntracers, void* f, const void* u, const void* w, const void* rho,

@@ -302,9 +302,9 @@ hipError_t mpdata_layout_convert_cols(const MpdataLayoutJob* jobs, int nj, bool 
   const int nlev = jobs[0].nlev;
   // instances per workgroup: 8 elements per thread and column
   // (an export is 7 % faster with twice as many, half as wide workgroups; an import is not)
-  // (nz > 64, one instance per tile: 16 instances per workgroup)
-  if (nlev > 128) return hipErrorInvalidValue;
-  const int ti = nlev > 64 ? 16 : (!to_private ? 32 : (nlev * 64 <= 2048 ? 64 : 32));
+  // (nz > 64, one instance per tile: 16 instances per workgroup, 8 above 128 levels)
+  if (nlev > 256) return hipErrorInvalidValue;
+  const int ti = nlev > 128 ? 8 : nlev > 64 ? 16 : (!to_private ? 32 : (nlev * 64 <= 2048 ? 64 : 32));
   const dim3 grid((unsigned)((nc + ti - 1) / ti), 1, (unsigned)(nj * js.ntr_max)), block(256);
   const size_t lds = (size_t)2 * nlev * (ti + 1) * 8;
   if (ti == 64) {
@@ -313,6 +313,9 @@ hipError_t mpdata_layout_convert_cols(const MpdataLayoutJob* jobs, int nj, bool 
   } else if (ti == 16) {
     if (to_private) hipLaunchKernelGGL((wm_convert_cols_kernel<double, 16, true>), grid, block, lds, stream, js);
     else hipLaunchKernelGGL((wm_convert_cols_kernel<double, 16, false>), grid, block, lds, stream, js);
+  } else if (ti == 8) {
+    if (to_private) hipLaunchKernelGGL((wm_convert_cols_kernel<double, 8, true>), grid, block, lds, stream, js);
+    else hipLaunchKernelGGL((wm_convert_cols_kernel<double, 8, false>), grid, block, lds, stream, js);
   } else {
     if (to_private) hipLaunchKernelGGL((wm_convert_cols_kernel<double, 32, true>), grid, block, lds, stream, js);
     else hipLaunchKernelGGL((wm_convert_cols_kernel<double, 32, false>), grid, block, lds, stream, js);

@@ -119,9 +119,9 @@ MpdataLayoutJob wm_job(const mpdata_plan* p, int which, void* ref, int first_tra
   return j;
 }
 
-// lanes per instance of the wave-major kernels; 128 = an instance wider than a wave (65 <= nz <= 127: several waves
+// lanes per instance of the wave-major kernels; 128 = an instance wider than a wave (65 <= nz <= 238: several waves
 // per instance, mpdata_kernel_wm_body.h "KS"; the layout kernels hold a column of one instance group in LDS: nzm <= 126)
-#define MPDATA_WM_NZ_MAX 127
+#define MPDATA_WM_NZ_MAX 238   // 64 + 3 * 58: four windows = the four waves of a workgroup
 int wm_lps_for(int nz) { return nz <= 8 ? 8 : nz <= 16 ? 16 : nz <= 32 ? 32 : nz <= 64 ? 64 : nz <= MPDATA_WM_NZ_MAX ? 128 : 0; }
 int wm_nkw_for(int nz) { return nz <= 64 ? 1 : 1 + (nz - 64 + 57) / 58; }
 // nz > 64: lanes of the last window where it is a share of a wave (16: the window needs <= 16 levels, 32: <= 32; else 0 = a
@@ -767,7 +767,7 @@ int mpdata_plan_destroy(mpdata_plan* p) {
   return 0;
 }
 
-// ---- calls on reference-layout device arrays with 65 <= nz <= 127 (round 5).  No x-marching kernel holds such an
+// ---- calls on reference-layout device arrays with 65 <= nz <= 238 (round 5).  No x-marching kernel holds such an
 //      instance in a wave and the k-marching fall-back runs at 13-16 Gcu/s (fp64, nx <= 140 only; fp32: nothing).  Such
 //      a call goes through a wave-major plan kept per host thread instead: import f, u, w, rho, rhow, adz, flux
 //      (the layout kernels), the plan kernel (several waves per instance), export f and flux -- everything on the

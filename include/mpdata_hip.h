@@ -90,7 +90,7 @@ int mpdata_advect_scalar2d(int64_t ncrms, int nx, int nz, int ntracers,
  * set; a thread that ends releases its own; MPDATA_HOST_CACHE=0 in the environment keeps nothing.
  * The same call releases the park arrays that EXACT calls on reference-layout DEVICE arrays keep per
  * host thread and stream (only where the limited fluxes do not fit registers: nx > 36, nz 33 .. 64), and
- * the wave-major plan that calls on reference-layout device arrays with 65 <= nz <= 127 run through
+ * the wave-major plan that calls on reference-layout device arrays with 65 <= nz <= 238 run through
  * (the size of the call's arrays; kept per host thread for the next call of the same shape). */
 int mpdata_release_host_buffers(void);
 
@@ -99,10 +99,10 @@ int mpdata_release_host_buffers(void);
  * reference's timed region (:110-238: kernels only, data already on the
  * device).  Arrays cover `ncrms` CRM instances with leading dimension
  * `ncrms`.  In-place on f.  nz <= 64: one kernel on the caller's arrays.
- * 65 <= nz <= 127: through a wave-major plan kept per host thread (import,
+ * 65 <= nz <= 238: through a wave-major plan kept per host thread (import,
  * plan kernel, export, all on `stream`; the first call of a shape allocates;
  * MPDATA_DEVICE_CALL=direct: the k-marching kernel on the caller's arrays,
- * a third of the rate).  nz > 127: the k-marching kernel (fp64, nx <= 140). */
+ * a third of the rate).  nz > 238: the k-marching kernel (fp64, nx <= 140). */
 int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers,
                                   double* f, const double* u, const double* w,
                                   const double* rho, const double* rhow,
@@ -115,11 +115,11 @@ int mpdata_advect_scalar2d_device(int64_t ncrms, int nx, int nz, int ntracers,
  * fixes the kernel variant at creation.
  *
  * Device layout.  The arrays a caller passes are ALWAYS in the reference
- * layout above.  Inside a plan with nz <= 127 (fp64; fp32 with an even ncrms) the library keeps them in
+ * layout above.  Inside a plan with nz <= 238 (fp64; fp32 with an even ncrms) the library keeps them in
  * its own "wave-major" order -- [tile of 64/LPS adjacent instances][column]
  * [instance][level], LPS = 8/16/32/64 >= nz (nz > 64: one instance per tile, worked on by several waves) -- so that
  * every wave streams contiguous memory; upload / download / import / export
- * convert on the device.  Other plans (nz > 127; fp32 with an odd ncrms), MPDATA_PLAN_LAYOUT=
+ * convert on the device.  Other plans (nz > 238; fp32 with an odd ncrms), MPDATA_PLAN_LAYOUT=
  * reference or mpdata_set_plan_layout(MPDATA_LAYOUT_REFERENCE) keep the
  * reference layout.  Results do not depend on the layout. */
 #define MPDATA_LAYOUT_REFERENCE 0

@@ -40,9 +40,9 @@ def test_argument_errors_without_device(mpdata):
         assert b"bad sizes" in L.mpdata_last_error()
     rc = L.mpdata_advect_scalar2d_device(4, 8, 6, 1, None, one, one, one, one, one, one, None)
     assert rc == -1
-    # nz beyond the wave-major forms (x-marching kernels: 64, window form: 127) AND nx beyond the widest k-marching
+    # nz beyond the wave-major forms (x-marching kernels: 64, window form: 238) AND nx beyond the widest k-marching
     # tiling -> MPDATA_EUNSUPPORTED
-    rc = L.mpdata_advect_scalar2d_device(4, 4000, 130, 1, one, one, one, one, one, one, one, None)
+    rc = L.mpdata_advect_scalar2d_device(4, 4000, 300, 1, one, one, one, one, one, one, one, None)
     assert rc == -2
     p = ctypes.c_void_p()
     assert L.mpdata_plan_create(4, 8, 2, 1, ctypes.byref(p)) == -1 and not p.value

@@ -118,9 +118,9 @@ def test_fp32_ragged_and_edge_shapes(M, oracle, shape, variant):
 
 
 def test_fp32_unsupported_shapes_fail_loudly(M, oracle):
-    """Odd ncrms needs nz <= 32; nz > 127 has no fp32 kernel (65 .. 127 with an even ncrms: through the calling thread's
+    """Odd ncrms needs nz <= 32; nz > 238 has no fp32 kernel (65 .. 238 with an even ncrms: through the calling thread's
     wave-major plan since round 5): an error, never a fallback."""
-    for shape in ((9, 6, 33), (5, 10, 65), (6, 10, 130)):
+    for shape in ((9, 6, 33), (5, 10, 65), (6, 10, 239)):
         inp = oracle.make_inputs(*shape, seed=3, dist=1, dtype=F32)
         with pytest.raises(M.MpdataError) as ei:
             run_hip(M, inp)

@@ -15,12 +15,15 @@ from util import max_abs, to_dev, to_host
 pytestmark = pytest.mark.gpu
 
 # nz: the first size of the form (65), seams at every parity (koff of the last wave = the even number >= nz - 64),
-# the largest two-wave size (122), three waves (123 ... 127 = the largest the layout kernels take)
+# the largest two-wave size (122), three waves (123 ... 180), four (181 ... 238)
 # (nz <= 74 / <= 90: the last window is a 16- / 32-lane share of a wave that holds those of 4 / 2 instances -- workgroups
 #  of 3 / 2 instances: ncrms at every remainder; 74 | 75 and 90 | 91 are the seams between the forms)
 SHAPES = [(9, 32, 72), (4, 5, 65), (3, 7, 66), (5, 12, 67), (6, 3, 100), (3, 7, 121), (2, 9, 122), (3, 4, 123),
           (5, 12, 127), (130, 32, 72), (67, 33, 90), (7, 9, 74), (5, 11, 75), (1, 4, 70), (2, 6, 80), (11, 5, 91),
-          (10, 8, 89), (3, 40, 73), (131, 13, 81)]
+          (10, 8, 89), (3, 40, 73), (131, 13, 81),
+          # above 127 levels (three and four windows; the layout kernels take 8 instances per workgroup there); 238 = 64 + 3 * 58
+          # is the largest: four windows = the four waves of a workgroup
+          (3, 5, 128), (2, 7, 129), (4, 6, 180), (5, 9, 181), (2, 4, 238), (18, 11, 200)]
 
 
 @pytest.fixture(autouse=True)
@@ -67,7 +70,7 @@ def test_shapes_above_64_levels(mpdata, oracle, shape, variant, dist):
 
 
 @pytest.mark.parametrize("shape,ntr", [((9, 32, 72), 3), ((21, 7, 100), 2), ((4, 12, 125), 5), ((7, 10, 80), 4),
-                                       ((5, 9, 66), 5), ((20, 6, 74), 2)])
+                                       ((5, 9, 66), 5), ((20, 6, 74), 2), ((3, 6, 150), 2), ((2, 5, 238), 3)])
 @pytest.mark.parametrize("variant", ["exact", "fast"])
 def test_tracer_batches_above_64_levels(mpdata, oracle, shape, ntr, variant):
     M = mpdata
@@ -216,7 +219,7 @@ def test_4096_instances_of_72_levels_and_its_rate(mpdata, oracle):
     assert frac >= 0.40, (ms, frac)
 
 
-@pytest.mark.parametrize("shape", [(10, 9, 72), (4, 5, 65), (6, 12, 127), (130, 32, 72), (10, 7, 80), (14, 5, 90)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(10, 9, 72), (4, 5, 65), (6, 12, 127), (130, 32, 72), (10, 7, 80), (14, 5, 90), (4, 5, 200), (6, 3, 130)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("variant", ["exact", "fast"])
 def test_fp32_plans_above_64_levels(mpdata, oracle, shape, variant):
     """fp32 plans with an even ncrms (two adjacent instances per lane) at nz > 64: the same several-waves-per-instance form
@@ -308,7 +311,7 @@ def test_sibling_waves_do_not_overtake_each_other(mpdata, oracle, variant, nz, n
                 assert max_abs(fg, fr) < 1e-12 and max_abs(flg[:, :nzm], flr[:, :nzm]) < 1e-12
 
 
-# ---- calls on reference-layout DEVICE arrays (mpdata_advect_scalar2d_device, the Fortran drivers' call) at nz 65 .. 127:
+# ---- calls on reference-layout DEVICE arrays (mpdata_advect_scalar2d_device, the Fortran drivers' call) at nz 65 .. 238:
 #      through a wave-major plan the library keeps per host thread (csrc/mpdata_plan.hip: staged_device_call) -- up to
 #      round 5 the k-marching kernel (13-16 Gcu/s; fp32 and nx > 140: MPDATA_EUNSUPPORTED)
 def _stack(oracle, shape, ntr, dtype=np.float64, dist=3):
@@ -323,7 +326,8 @@ def _stack(oracle, shape, ntr, dtype=np.float64, dist=3):
     return base, fs, inp
 
 
-@pytest.mark.parametrize("shape,ntr", [((9, 32, 72), 1), ((4, 150, 70), 1), ((3, 7, 127), 1), ((21, 12, 100), 3), ((5, 70, 66), 2)],
+@pytest.mark.parametrize("shape,ntr", [((9, 32, 72), 1), ((4, 150, 70), 1), ((3, 7, 127), 1), ((21, 12, 100), 3), ((5, 70, 66), 2),
+                                       ((3, 7, 200), 1), ((2, 70, 238), 2)],
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
 @pytest.mark.parametrize("variant", ["exact", "fast"])
 def test_device_call_above_64_levels(mpdata, oracle, shape, ntr, variant):
@@ -434,3 +438,21 @@ def test_arrays_larger_than_4GiB_at_72_levels(mpdata, oracle):
     del d
     M.release_host_buffers()
     torch.cuda.empty_cache()
+
+
+def test_above_238_levels_the_reference_layout(mpdata, oracle):
+    """nz > 238 (more than four windows): the plan keeps the reference layout and runs the k-marching kernel -- correct,
+    a tenth of the rate"""
+    M = mpdata
+    M.set_variant(M.VARIANT_EXACT)
+    shape = (5, 6, 239)
+    inp = oracle.make_inputs(*shape, seed=5, dist=3)
+    p = M.Plan(*shape, 1)
+    assert p.layout == M.LAYOUT_REFERENCE
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run(); p.sync()
+    f = np.empty_like(inp["f"], order="F"); flux = np.empty_like(inp["flux"], order="F")
+    p.download(f, flux)
+    p.close()
+    f_ref, flux_ref = oracle.advect(inp, nthreads=4)
+    assert np.array_equal(f, f_ref) and np.array_equal(flux, flux_ref)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off wider sweep than the test suite over round 5's kernel changes (GPU): random shapes through mpdata_plan_run
-with nz 3 .. 127 (every lane mapping; above 64 levels several waves per instance), nx 1 .. 40, 1 .. 6 tracers (even and
+with nz 3 .. 238 (every lane mapping; above 64 levels several waves per instance), nx 1 .. 40, 1 .. 6 tracers (even and
 odd: the one-launch batch with an odd tracer), ncrms 1 .. 700, the three input laws:
   * EXACT: f AND flux bit-identical to the oracle (the register park at nx <= 36, the park array beyond);
   * FAST: within 1e-12 on conditioned inputs, rel-L1 < 1e-14 otherwise;
@@ -48,7 +48,7 @@ def plan_run(inp, shape, T, dtype=np.float64):
 
 
 for it in range(n):
-    shape = rshape(127)
+    shape = rshape(238)
     T = int(rng.integers(1, 7)) if it % 3 == 0 else 1
     dist = int(rng.integers(1, 4))
     variant = M.VARIANT_EXACT if it % 2 == 0 else M.VARIANT_FAST
@@ -103,7 +103,7 @@ for it in range(n):
 M.set_variant(M.VARIANT_EXACT)
 from util import to_dev, to_host
 for it in range(n // 2):
-    shape = rshape(127)
+    shape = rshape(238)
     T = int(rng.integers(2, 6))
     base = O.make_inputs(*shape, seed=17000 + it, dist=3)
     fs = [O.make_inputs(*shape, seed=18000 + 10 * it + t, dist=3)["f"] for t in range(T)]
