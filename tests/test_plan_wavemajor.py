@@ -369,12 +369,15 @@ def test_exact_flux_without_the_park_array(oracle):
         "import codesign_kernels_amd as M\n"
         "from oracle import oracle as O\n"
         "O.build_lib(); M.set_variant(M.VARIANT_EXACT)\n"
-        "inp = O.make_inputs(130, 31, 28, seed=5, dist=3)\n"
-        "p = M.Plan(130, 31, 28, 1); p.upload(inp['f'], inp['u'], inp['w'], inp['rho'], inp['rhow'], inp['adz'], inp['flux']); p.run(); p.sync()\n"
-        "f = np.empty_like(inp['f'], order='F'); fl = np.empty_like(inp['flux'], order='F'); p.download(f, fl); p.close()\n"
-        "fr, flr = O.advect(inp, nthreads=2)\n"
-        "d = np.abs(fl[:, :-1] - flr[:, :-1]); tol = 1e-13 * np.maximum(1.0, np.abs(flr[:, :-1]))\n"
-        "print('RESULT ' + json.dumps({'f': bool(np.array_equal(f, fr)), 'flux_close': bool(np.all(d <= tol)), 'flux_equal': bool(np.array_equal(fl, flr))}))\n"
+        "res = {'f': True, 'flux_close': True, 'flux_equal': True}\n"
+        "for shape in ((130, 31, 28), (9, 20, 72), (7, 11, 80), (5, 9, 130)):\n"
+        "    inp = O.make_inputs(*shape, seed=5, dist=3)\n"
+        "    p = M.Plan(*shape, 1); p.upload(inp['f'], inp['u'], inp['w'], inp['rho'], inp['rhow'], inp['adz'], inp['flux']); p.run(); p.sync()\n"
+        "    f = np.empty_like(inp['f'], order='F'); fl = np.empty_like(inp['flux'], order='F'); p.download(f, fl); p.close()\n"
+        "    fr, flr = O.advect(inp, nthreads=2)\n"
+        "    d = np.abs(fl[:, :-1] - flr[:, :-1]); tol = 1e-13 * np.maximum(1.0, np.abs(flr[:, :-1]))\n"
+        "    res['f'] &= bool(np.array_equal(f, fr)); res['flux_close'] &= bool(np.all(d <= tol)); res['flux_equal'] &= bool(np.array_equal(fl, flr))\n"
+        "print('RESULT ' + json.dumps(res))\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPDATA_EXACT_FLUX="sum"), capture_output=True,
                        text=True, timeout=300, cwd=ROOT)
