@@ -6,8 +6,24 @@
 #include "mpdata_kernel_v2_body.h"
 #include "mpdata_kernel_wm_body.h"
 
+// One variant is compiled as FOUR translation units (make -j: the kernels are the build time): -DMPDATA_PART=
+//   0  the kernels of the calls on reference-layout arrays (x-march, k-march), tile table, build flags
+//   1  the plan kernels for nz <= 64 (launch_wm, launch_wm_f32)
+//   2  the plan kernels for nz > 64 (window form, tail form)
+//   3  the plan kernels that read u, w from the reference layout (launch_wm_uw)
+// (no MPDATA_PART: everything in one unit)
+#ifndef MPDATA_PART
+#define MPDATA_PART -1
+#endif
+#define MPD_PART(n) (MPDATA_PART < 0 || MPDATA_PART == (n))
+
 namespace MPDATA_NS {
 
+// nz > 64: defined in part 2, called from launch_wm / launch_wm_f32 (part 1)
+void launch_wm_ks_f64(const MpdataWmArgsT<double>& a, void* stream);
+void launch_wm_ks_f32(const MpdataWmArgsT<v2::f32x2>& a, void* stream);
+
+#if MPD_PART(0)
 template <int W, int SPW, int NWV>
 static void launch_tile(const MpdataArgs& a, int ntracers, void* stream) {
   using T = Tile<W, SPW, NWV>;
@@ -91,12 +107,15 @@ static void launch_tile_v2(const MpdataArgsT<R>& a, int ntracers, void* stream) 
 #endif
 }
 
+#endif   // part 0
+
 // wave-major kernels (mpdata_kernel_wm_body.h, the plan API): LPS = lanes per instance (>= nz),
 // WPB = waves per workgroup.  Returns false if (lps, wpb) is not instantiated.
 #define MPDATA_WM_LPS(X) X(8) X(16) X(32) X(64)
 // waves (= tiles) per workgroup of the plan kernels; the waves of a workgroup never synchronise, the workgroup is
 // only the unit in which the dispatcher hands out wave slots and LDS (1, 2, 4, 8 measured alike, profiles/r04_ablation.json)
 #define MPDWM_WPB 4
+#if MPD_PART(1)
 template <typename R, int LPS, int WPB>
 static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
   // ntracers == 1: wave = tile in dispatch order, u and w streamed; else the per-XCD tracer walk with
@@ -179,6 +198,8 @@ static void launch_wm_t(const MpdataWmArgsT<R>& a, void* stream, int flags) {
     }
   }
 }
+#endif   // part 1
+#if MPD_PART(2)
 // nz > 64 (kernel form LPS = 128): a.nkw waves per instance and tracer, one tracer per wave, the batch form of the
 // data movement; EXACT with the register park (the caller makes sure that nx <= MPDATA_WM_NPK or that no flux order
 // is asked for)
@@ -261,10 +282,14 @@ static void launch_wm_ks2(const MpdataWmArgsT<R>& a_in, void* stream) {
   KS2_LAUNCH(1, 0, a.ntracers)
 #undef KS2_LAUNCH
 }
+void launch_wm_ks_f64(const MpdataWmArgsT<double>& a, void* stream) { launch_wm_ks<double>(a, stream); }
+void launch_wm_ks_f32(const MpdataWmArgsT<v2::f32x2>& a, void* stream) { launch_wm_ks<v2::f32x2>(a, stream); }
+#endif   // part 2
+#if MPD_PART(1)
 bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags) {
   if (wpb != MPDWM_WPB) return false;
   if (lps == 128) {
-    launch_wm_ks<double>(a, stream);
+    launch_wm_ks_f64(a, stream);
     return true;
   }
 #define X(LPS_)                             \
@@ -276,6 +301,8 @@ bool launch_wm(int lps, int wpb, const MpdataWmArgs& a, void* stream, int flags)
 #undef X
   return false;
 }
+#endif   // part 1
+#if MPD_PART(3)
 // mpdata_plan_run_uw, one fp64 tracer: u, w read from the REFERENCE layout (a.u_ref, a.w_ref), f in
 // the plan layout; workgroups of 16 adjacent instances (16 / SLP waves)
 bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream, bool conv) {
@@ -300,6 +327,8 @@ bool launch_wm_uw(int lps, const MpdataWmArgs& a, void* stream, bool conv) {
 #undef X
   return false;
 }
+#endif   // part 3
+#if MPD_PART(1)
 // fp32 plans: two adjacent instances per lane (8-byte elements = pairs of fp32 values, packed
 // arithmetic); `a` describes the arrays in PAIRS (ncrms / 2 of them)
 bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stream, int flags) {
@@ -318,7 +347,7 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   a.nkw = a8.nkw;
   a.lwt = a8.lwt;
   if (lps == 128) {
-    launch_wm_ks<v2::f32x2>(a, stream);
+    launch_wm_ks_f32(a, stream);
     return true;
   }
 #define X(LPS_)                                \
@@ -331,6 +360,8 @@ bool launch_wm_f32(int lps, int wpb, const MpdataWmArgsT<double>& a8, void* stre
   return false;
 }
 
+#endif   // part 1
+#if MPD_PART(0)
 int max_tile_id() { return 43; }
 
 // Experiment / timing-ablation macros this translation unit was compiled with (some of them
@@ -452,5 +483,6 @@ bool launch_f32(int id, const MpdataArgsF32& a, int ntracers, void* stream) {
   }
   return false;
 }
+#endif   // part 0
 
 }  // namespace MPDATA_NS

@@ -84,7 +84,7 @@ def test_default_kernels_do_not_spill():
     objects."""
     import glob
     reports = glob.glob(os.path.join(ROOT, "codesign-kernels_amd", "csrc", "mpdata_kernels_*.usage.txt"))
-    reports = [r for r in reports if re.fullmatch(r"mpdata_kernels_(exact|fast)\.usage\.txt", os.path.basename(r))]
+    reports = [r for r in reports if re.fullmatch(r"mpdata_kernels_(exact|fast)_p\d\.usage\.txt", os.path.basename(r))]
     if not reports:
         pytest.skip("no resource-usage report (library not built here)")
     seen = 0
