@@ -40,7 +40,7 @@ r = d["roofline"]
 s = s[:i] + ("Round-5 record (builder's box, the FINAL library, driver arguments `--gpus 1 --steps 20 --warmup 5`;\n"
              "profiles/%s_bench_driver.json): the timed average sits %.1f %% %s the per-launch median, `frac_of_measured_ceiling` %.3f;\n"
              "kernel trace and PMC passes: %s_kernel_stats.csv, %s_pmc_summary.json.  Boxes differ by 2–3 %% on one binary.  Other\n"
-             "shapes (%s_shape_sweep.txt; nx 32 … 256, nz 28 … 110): FAST 0.62–0.68, nz = 125 0.54." % (
+             "shapes (%s_shape_sweep.txt; nx 32 … 256, nz 28 … 110): FAST 0.62–0.70, nz = 125 0.54." % (
                  tag, abs(r["avg_over_median"] - 1) * 100, "above" if r["avg_over_median"] > 1 else "below",
                  r["frac_of_measured_ceiling"], tag, tag, tag)) + s[j:]
 open(path, "w").write(s)
