@@ -1214,10 +1214,11 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 // LPS = 128 + LWT) beside the instances' full-width waves.  A workgroup = a.ksg instances = ksg full-width waves +
 // ceil(ksg LWT / 64) tail waves, which meet in the barrier of the column pairs like the waves of the plain form.  ksg is
 // 3 at LWT = 16 (3 + 1 = FOUR waves: 85 lanes per instance instead of 128) and 2 at LWT = 32 (2 + 1 waves: 96 lanes).
-// With 4 + 1 waves at LWT = 16 only ONE workgroup was ever resident on a CU (measured: 4.8 waves per CU on average,
-// where registers and LDS allow ten; the cause was not established -- workgroups of three and of four waves reach 10.5
-// and more) and the form was no faster than the plain one at 38 % fewer instructions; 5 + 3 = eight waves at LWT = 32
-// (one workgroup per CU at three waves per SIMD) lost against 2 + 1.
+// With 4 + 1 waves at LWT = 16 only ONE workgroup was ever resident on a CU (4.8 waves per CU on average) and the form
+// was no faster than the plain one at 38 % fewer instructions: a workgroup takes ceil(waves / 4) wave slots on EVERY
+// SIMD of its CU (tools/wg_residency.hip, profiles/r05_wg_residency.txt), so five to eight waves cost two slots per
+// SIMD -- of the three a SIMD has at more than 128 registers.  Hence 3 + 1; 5 + 3 = eight waves at LWT = 32 (one workgroup
+// per CU) and 4 + 2 lost against 2 + 1.
 // Three waves per SIMD (134 registers, FAST): at four (128 registers, 24 bytes of scratch) 3 % slower.
 // LDS: a ring per wave, sized by the launch.
 template <typename R, int LWT, int TPW = 1, int NPK = 0>
