@@ -28,7 +28,9 @@ def test_live_line_meets_the_contract():
     keys = list(d)
     assert keys.index("tracer_batched") > keys.index("consecutive_tracers_shared_uw") > keys.index("layout_conversion")
     assert keys.index("exact_variant") > keys.index("cpu_baseline") > keys.index("consecutive_tracers_shared_uw")
-    assert keys[-1] == "tracer_batched" and keys.index("roofline") < keys.index("layout_conversion")
+    assert keys[-2] == "tracer_batched" and keys.index("roofline") < keys.index("layout_conversion")
+    assert keys[-1] == "headline_repeated" and d["headline_repeated"]["value"] == d["value"] \
+        and d["headline_repeated"]["roofline_frac"] == d["roofline"]["frac"]
     C.check_headline(d, 8192)
     C.check_roofline(d, 8192)
     C.check_cpu_baseline(d)
