@@ -393,7 +393,7 @@ def ordered_for_the_tail(d):
     r = d.get("roofline") or {}
     out["headline_repeated"] = {"metric": d.get("metric"), "value": d.get("value"), "unit": d.get("unit"), "n_gpus": d.get("n_gpus"),
                                 "ms_per_step": d.get("ms_per_step"), "roofline_frac": r.get("frac"),
-                                "kernel_ms_avg": r.get("kernel_ms_avg"), "workload": (d.get("config") or {}).get("workload")}
+                                "kernel_ms_avg": r.get("kernel_ms_avg")}
     return out
 
 
