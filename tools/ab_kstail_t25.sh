@@ -1,7 +1,9 @@
 #!/bin/bash
-# 25 tracers at 72 levels, bench.py's cold protocol: tail form against whole-wave windows (MPDATA_KS_TAIL=0), FAST; interleaved.
+# usage: bash tools/ab_kstail_t25.sh [nz ncrms]
+# 25 tracers at 72 levels (default), bench.py's cold protocol: tail form against whole-wave windows (MPDATA_KS_TAIL=0), FAST; interleaved.
 mkdir -p gpurun_out; L=gpurun_out/ab_kstail_t25.log; : > $L
-X="--nz 72 --ncrms-per-gpu 24576 --steps 10 --warmup 3 --no-fp32 --no-bwk --no-exact --no-host-call --no-reflayout --no-x2 --no-shared-block --no-fresh-uw --no-cpu-baseline"
+NZ=${1:-72}; NC=${2:-24576}
+X="--nz $NZ --ncrms-per-gpu $NC --steps 10 --warmup 3 --no-fp32 --no-bwk --no-exact --no-host-call --no-reflayout --no-x2 --no-shared-block --no-fresh-uw --no-cpu-baseline"
 for i in 1 2; do
   for t in 1 0; do
     MPDATA_KS_TAIL=$t timeout -k 10 300 python bench.py $X > gpurun_out/ab_kstail_t25.json 2>/dev/null || exit 1
