@@ -378,7 +378,7 @@ class Plan:
     """Library-owned device state + stream (reference: `!$acc enter data`,
     `update device`, `wait`, `update host`; :105-110, :237-242).  Arrays cross
     the boundary in the reference layout; the plan keeps them in its own layout
-    (`layout`: LAYOUT_WAVEMAJOR for fp64 with nz <= 64, include/mpdata_hip.h 3)."""
+    (`layout`: LAYOUT_WAVEMAJOR for nz <= 238 -- fp32: an even ncrms --, include/mpdata_hip.h 3)."""
 
     def __init__(self, ncrms, nx, nz, ntracers=1, dtype=np.float64, ngpus=None, devices=None):
         """ngpus / devices: a multi-GPU plan (include/mpdata_hip.h section 3b) -- the problem

@@ -237,9 +237,9 @@ int mpdata_unpack_shard_device(double* full, const double* shard, int64_t rows, 
 
 /* ---- 6. fp32: the reference's precision switch (`rp`, reference :12-13; note that the
  * `selected_real_kind(7)` it asks for is fp64 on conforming compilers -- IEEE single is
- * `selected_real_kind(6)`).  Same array contract with 4-byte reals.  Kernels cover nz <= 64
- * for even ncrms (two adjacent instances per lane, packed fp32 arithmetic) and nz <= 32 for
- * odd ncrms.  EXACT variant: f bit-identical to an fp32 build of the reference. */
+ * `selected_real_kind(6)`).  Same array contract with 4-byte reals.  Kernels cover nz <= 238
+ * for even ncrms (two adjacent instances per lane, packed fp32 arithmetic; above 64 levels through
+ * a wave-major plan, as the fp64 device call) and nz <= 32 for odd ncrms.  EXACT variant: f bit-identical to an fp32 build of the reference. */
 int mpdata_advect_scalar2d_f32(int64_t ncrms, int nx, int nz, int ntracers,
                                float* f, const float* u, const float* w,
                                const float* rho, const float* rhow,
