@@ -456,3 +456,35 @@ def test_above_238_levels_the_reference_layout(mpdata, oracle):
     p.close()
     f_ref, flux_ref = oracle.advect(inp, nthreads=4)
     assert np.array_equal(f, f_ref) and np.array_equal(flux, flux_ref)
+
+
+@pytest.mark.parametrize("shape,ntr", [((10, 9, 72), 3), ((8, 7, 80), 2), ((6, 5, 130), 4), ((12, 40, 70), 2)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_fp32_tracer_batches_above_64_levels(mpdata, oracle, shape, ntr, variant):
+    """fp32 tracer batches at nz > 64 (FAST: two tracers per wave in the `float2` forms of the window and tail kernels;
+    EXACT: one tracer per wave, register park at nx <= 36, 66-column park / park array beyond): every tracer against a
+    single-tracer call of the fp32 oracle"""
+    M = mpdata
+    F32 = np.float32
+    var = M.VARIANT_EXACT if variant == "exact" else M.VARIANT_FAST
+    M.set_variant(var)
+    base = oracle.make_inputs(*shape, seed=21, dist=1, dtype=F32)
+    fs = [oracle.make_inputs(*shape, seed=300 + t, dist=1, dtype=F32)["f"] for t in range(ntr)]
+    inp = dict(base, f=np.asfortranarray(np.stack(fs, axis=-1)), flux=np.asfortranarray(np.stack([base["flux"]] * ntr, axis=-1)))
+    p = M.Plan(*shape, ntr, dtype=F32)
+    assert p.layout == M.LAYOUT_WAVEMAJOR
+    p.upload(inp["f"], inp["u"], inp["w"], inp["rho"], inp["rhow"], inp["adz"], inp["flux"])
+    p.run(); p.sync()
+    f = np.empty_like(inp["f"], order="F"); flux = np.empty_like(inp["flux"], order="F")
+    p.download(f, flux)
+    p.close()
+    nzm = shape[2] - 1
+    for t in range(ntr):
+        f_ref, flux_ref = oracle.advect(dict(base, f=fs[t].copy()))
+        if var == M.VARIANT_EXACT:
+            assert np.array_equal(f[..., t], f_ref) and np.array_equal(flux[..., t], flux_ref), t
+        else:
+            assert np.abs(f[..., t].astype(np.float64) - f_ref).max() < 1e-5, t
+            d = np.abs(flux[:, :nzm, t].astype(np.float64) - flux_ref[:, :nzm])
+            assert np.all(d <= 2e-5 * np.maximum(1.0, np.abs(flux_ref[:, :nzm]))), t
