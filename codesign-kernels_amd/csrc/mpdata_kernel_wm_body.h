@@ -1117,9 +1117,22 @@ __device__ __forceinline__ void wm_body(const MpdataWmArgsT<R>& a, R* const lds,
       okf = kk2 < nzm;
       posf = (l2 / LW) * nzm + (okf ? kk2 : nzm - 1);
     }
-    if (okf && tile_ok) flux[posf] = first(fl);
-    if constexpr (TPW == 2)
-      if (out_ok && has1 && tile_ok) flux1[pos] = second(fl);
+    if constexpr (KT) {   // tail waves: tile and element of the lane formed again behind the march (three registers the
+                          // 66-column register park does not have)
+      unsigned z;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      const int l2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+      const int s2 = l2 / LW, k2 = l2 % LW + koff + 1;
+      const bool ok2 = k2 <= nzm && s2 < ntl && k2 >= 58 * kwave + 4;   // (= out_ok: the tail is an instance's LAST window)
+      R* const fl2 = a.flux + (long long)tr * a.flux_tstride + ((long long)tile + (s2 < ntl ? s2 : 0)) * chunk;
+      if (ok2) fl2[k2 - 1] = first(fl);
+      if constexpr (TPW == 2)
+        if (ok2 && has1) fl2[a.flux_tstride + (k2 - 1)] = second(fl);
+    } else {
+      if (okf && tile_ok) flux[posf] = first(fl);
+      if constexpr (TPW == 2)
+        if (out_ok && has1 && tile_ok) flux1[pos] = second(fl);
+    }
   }
 #ifdef MPDWM_STAMPS
   if (a.dbg) {

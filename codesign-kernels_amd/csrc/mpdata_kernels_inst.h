@@ -208,13 +208,8 @@ static void launch_wm_ks2(const MpdataWmArgsT<R>& a, void* stream);
 template <typename R>
 static void launch_wm_ks(const MpdataWmArgsT<R>& a, void* stream) {
   constexpr int WPB = MPDWM_WPB;
-  // a short last window: the tail form (mpdata_advect_wm_ks2_kernel); not with the 66-column register park (EXACT,
-  // nx 37 .. 66: the tail wave's per-lane tile offsets are three registers more than the 256 there are)
-  bool tail = a.lwt != 0;
-#ifndef MPDATA_FAST_DIV
-  if (a.park_regs && a.nx > MPDATA_WM_NPK) tail = false;
-#endif
-  if (tail) {
+  // a short last window: the tail form (mpdata_advect_wm_ks2_kernel)
+  if (a.lwt != 0) {
     launch_wm_ks2<R>(a, stream);
     return;
   }
@@ -276,6 +271,7 @@ static void launch_wm_ks2(const MpdataWmArgsT<R>& a_in, void* stream) {
   }
 #ifndef MPDATA_FAST_DIV
   if (a.park_regs && a.nx <= MPDATA_WM_NPK) KS2_LAUNCH(1, MPDATA_WM_NPK, a.ntracers)
+  if (a.park_regs && a.nx <= MPDATA_WM_NPK2) KS2_LAUNCH(1, MPDATA_WM_NPK2, a.ntracers)
 #else
   if (a.ntracers >= 2) KS2_LAUNCH(2, 0, (a.ntracers + 1) / 2)
 #endif
