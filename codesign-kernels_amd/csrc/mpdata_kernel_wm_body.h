@@ -1232,7 +1232,7 @@ mpdata_advect_wm_kernel(const MpdataWmArgsT<R> a) {
 // SIMD of its CU (tools/wg_residency.hip, profiles/r05_wg_residency.txt), so five to eight waves cost two slots per
 // SIMD -- of the three a SIMD has at more than 128 registers.  Hence 3 + 1; 5 + 3 = eight waves at LWT = 32 (one workgroup
 // per CU) and 4 + 2 lost against 2 + 1.
-// Three waves per SIMD (134 registers, FAST): at four (128 registers, 24 bytes of scratch) 3 % slower.
+// Three waves per SIMD (130 registers, FAST): at four (128 registers, 20 bytes of scratch) equal to 1 % slower.
 // LDS: a ring per wave, sized by the launch.
 template <typename R, int LWT, int TPW = 1, int NPK = 0>
 __global__ void __launch_bounds__(64 * 4, ((TPW == 2 || NPK > 0) ? 2 : 3))
